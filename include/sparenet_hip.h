@@ -1,0 +1,202 @@
+/*
+ * sparenet_hip.h -- C ABI of libsparenet_hip.so, the MI355X (gfx950) native
+ * implementation of SpareNet's per-step loss / render hot path.
+ *
+ * Drop-in boundary: each entry point replaces one pybind function of the
+ * reference's torch C++ extensions under /root/reference/cuda/ (cited per
+ * function as file:line).  No torch types cross this boundary: every argument
+ * is a raw DEVICE pointer (hipMalloc'ed / torch CUDA-tensor storage), an int
+ * size or a float parameter, plus the hipStream_t (as void*) to launch on.
+ *
+ * Conventions
+ *   - all tensors are contiguous row-major fp32 / int32, sizes in elements;
+ *   - functions are asynchronous: they enqueue kernels on `stream` and return;
+ *   - return value: 0 (hipSuccess) on success; a positive hipError_t if a
+ *     launch failed; SN_EINVAL (-22) for rejected arguments (the reference
+ *     prints and carries on, asserts in Python or exit(-1)s; here every
+ *     failure is an error code + sn_last_error() text, and the Python mirror
+ *     raises);
+ *   - workspace: ops that need scratch take (workspace, workspace_bytes); the
+ *     matching sn_*_workspace_bytes() says how much.  Workspace contents need
+ *     no initialisation by the caller;
+ *   - thread safety: no global mutable state except the thread-local
+ *     last-error string; safe to call concurrently from several host threads
+ *     on different streams/devices (the reference is driven that way by
+ *     nn.DataParallel, runners/sparenet_runner.py:32-34).
+ */
+#ifndef SPARENET_HIP_H
+#define SPARENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_EINVAL (-22)
+#define SN_ABI_VERSION 1
+
+int sn_abi_version(void);
+/* thread-local text of the last failure on the calling thread ("" if none) */
+const char *sn_last_error(void);
+
+/* ------------------------------------------------------------------ Chamfer
+ * replaces cd.forward_cuda  = chamfer_distance_forward_cuda
+ *          (cuda/chamfer_distance/chamfer_distance.cpp:26-38,186;
+ *           kernel chamfer_distance.cu:7-155)
+ * dist1[b,j] = min_k |xyz1[b,j]-xyz2[b,k]|^2, idx1 = lowest k attaining it;
+ * symmetric for dist2/idx2.  b>=1, n>=1, m>=1. */
+int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n,
+                       int m, float *dist1, int *idx1, float *dist2,
+                       int *idx2, void *stream);
+/* replaces cd.backward_cuda = chamfer_distance_backward_cuda
+ *          (chamfer_distance.cpp:40-55,188; kernel chamfer_distance.cu:159-209)
+ * gradxyz1/gradxyz2 are fully overwritten (no pre-zeroing needed). */
+int sn_chamfer_backward(const float *xyz1, const float *xyz2,
+                        const float *graddist1, const float *graddist2,
+                        const int *idx1, const int *idx2, int b, int n, int m,
+                        float *gradxyz1, float *gradxyz2, void *stream);
+
+/* ---------------------------------------------------------------------- EMD
+ * replaces emd.forward = emd_forward -> emd_cuda_forward
+ *          (cuda/emd/emd.cpp:13-17,26; emd_cuda.cu:228-282) including the 12
+ *          scratch tensors the Python module allocates and initialises
+ *          (cuda/emd/emd_module.py:43-54): they live in `workspace` here.
+ * Requirements as the reference: n % 1024 == 0, b <= 512 (emd_module.py:36-39).
+ * dist[b,n] fp32, assignment[b,n] int32.
+ * stats (optional device pointer, may be NULL): 2 x int64
+ *   stats[0] += sum over iterations and batch of unassigned_count * n
+ *               (effective pair evaluations); stats[1] += iterations that had
+ *               at least one bidder.  The caller zeroes it. */
+size_t sn_emd_workspace_bytes(int b, int n);
+int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
+                   float eps, int iters, float *dist, int *assignment,
+                   void *workspace, size_t workspace_bytes,
+                   long long *stats, void *stream);
+/* replaces emd.backward = emd_backward -> emd_cuda_backward
+ *          (cuda/emd/emd.cpp:19-23,27; emd_cuda.cu:284-316)
+ * gradxyz1 is fully overwritten; gradient w.r.t. xyz2 is identically zero. */
+int sn_emd_backward(const float *xyz1, const float *xyz2,
+                    const float *graddist, const int *assignment, int b, int n,
+                    float *gradxyz1, void *stream);
+
+/* -------------------------------------------------------- expansion penalty
+ * replaces expansion_penalty.forward = expansion_penalty_forward
+ *          (cuda/expansion_penalty/expansion_penalty.cpp:8-12,20;
+ *           expansion_penalty_cuda.cu:7-165) without the two [b, n*512]
+ *          neighbor/cost scratch tensors
+ *          (expansion_penalty_module.py:33-34).
+ * primitive_size: power of two, 2..512, n % primitive_size == 0.
+ * mean_mst_length[b] is returned ALREADY divided by n/primitive_size
+ * (expansion_penalty_module.py:40 does that division in Python). */
+int sn_expansion_forward(const float *xyz, int b, int n, int primitive_size,
+                         float alpha, float *dist, int *assignment,
+                         float *mean_mst_length, void *stream);
+/* replaces expansion_penalty.backward (expansion_penalty.cpp:14-17,21;
+ *          expansion_penalty_cuda.cu:167-198); gradxyz fully overwritten. */
+int sn_expansion_backward(const float *xyz, const float *graddist,
+                          const int *assignment, int b, int n, float *gradxyz,
+                          void *stream);
+
+/* ---------------------------------------------------------------------- MDS
+ * replaces MDS.minimum_density_sampling (cuda/MDS/MDS.cpp:114-135,140;
+ *          kernel MDS_cuda.cu:91-268); the `temp` tensor MDS.cpp:119-121
+ *          allocates lives on-chip.  idx[b,m] int32. */
+int sn_mds(const float *xyz, int b, int n, int m, const float *mean_mst_length,
+           int *idx, void *stream);
+/* replaces MDS.gather_forward / MDS.gather_backward (MDS.cpp:54-113,138-139;
+ *          kernels MDS_cuda.cu:29-79). feat[b,c,n], idx[b,m], out[b,c,m].
+ * grad_feat is fully overwritten. */
+int sn_gather_forward(const float *feat, const int *idx, int b, int c, int n,
+                      int m, float *out, void *stream);
+int sn_gather_backward(const float *grad_out, const int *idx, int b, int c,
+                       int n, int m, float *grad_feat, void *stream);
+
+/* ---------------------------------------------------------------------- p2i
+ * replaces p2i_op.p2i_max_forward_gpu / p2i_max_backward_gpu
+ *          (cuda/p2i_op/ext.cpp:8-9; p2i_max.h:145-232; functors :7-143)
+ * points[npoints,2] pixel-space (row, col); feat[npoints,channels];
+ * batch_inds[npoints]; background[batch,channels,h,w].
+ * out/out_ids[batch,channels,h,w]; workspace holds the packed 64-bit image.
+ * Ties between equal splat values resolve to the LOWEST point id (the
+ * reference's GPU order is a race; its sequential CPU functor gives this). */
+size_t sn_p2i_max_workspace_bytes(int batch, int channels, int h, int w);
+int sn_p2i_max_forward(const float *points, const float *feat,
+                       const int *batch_inds, const float *background,
+                       int npoints, int channels, int batch, int h, int w,
+                       float radius, float *out, int *out_ids, void *workspace,
+                       size_t workspace_bytes, void *stream);
+/* points_grad[npoints,2], feat_grad[npoints,channels],
+ * background_grad[batch,channels,h,w] are fully overwritten. */
+int sn_p2i_max_backward(const float *out_grad, const int *out_ids,
+                        const float *points, const float *feat, int npoints,
+                        int channels, int batch, int h, int w, float radius,
+                        float *points_grad, float *feat_grad,
+                        float *background_grad, void *stream);
+/* replaces p2i_op.p2i_sum_forward_gpu / p2i_sum_backward_gpu
+ *          (cuda/p2i_op/ext.cpp:6-7; p2i_sum.h:133-214; functors :7-131)
+ * out must hold a copy of background on entry (the reference clones it,
+ * p2i_sum.h:147); it is accumulated in place. */
+int sn_p2i_sum_forward(const float *points, const float *feat,
+                       const int *batch_inds, int npoints, int channels,
+                       int batch, int h, int w, float radius, float *out,
+                       void *stream);
+int sn_p2i_sum_backward(const float *out_grad, const float *points,
+                        const float *feat, const int *batch_inds, int npoints,
+                        int channels, int batch, int h, int w, float radius,
+                        float *points_grad, float *feat_grad, void *stream);
+
+/* ------------------------------------------------- fused depth-map renderer
+ * replaces the tensor program of ComputeDepthMaps.forward
+ *          (utils/p2i_utils.py:211-252: transform :153-165, depth feature
+ *          :226-228, one p2i(max) per radius :230-251) for one view.
+ * data[b,n,3]; pre_matrix[16] row-major 4x4 (host pointer, proj @ view);
+ * zrange[2] device pointer = (min z, max z) over the transformed input,
+ * produced by sn_depth_zrange; out[b, nradius, s, s]; out_ids likewise.
+ * background is zero (p2i_utils.py:236-241). */
+size_t sn_depthmaps_workspace_bytes(int b, int nradius, int s);
+int sn_depth_zrange(const float *data, int b, int n, const float *pre_matrix,
+                    float *zrange, void *stream);
+int sn_depthmaps_forward(const float *data, int b, int n,
+                         const float *pre_matrix, const float *zrange,
+                         const float *radius_list, int nradius, int s,
+                         float *out, int *out_ids, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
+/* ----------------------------------------------------------------- gridding
+ * replaces gridding.forward / backward (cuda/gridding/gridding_cuda.cpp:44-67,
+ *          94-95; gridding.cu:29-211, 213-335).  ptcloud[b,npts,3] already
+ *          scaled; bounds are [-scale/2, scale/2-1] per axis as
+ *          cuda/gridding/__init__.py:16-19 passes them.
+ * grid[b,scale^3] fully overwritten; weights[b,npts,8,3]; indexes[b,npts,8]. */
+int sn_gridding_forward(const float *ptcloud, int b, int npts, int scale,
+                        float *grid, float *weights, int *indexes,
+                        void *stream);
+int sn_gridding_backward(const float *grad_grid, const float *weights,
+                         const int *indexes, int b, int npts, int nverts,
+                         float *grad_ptcloud, void *stream);
+/* replaces gridding.rev_forward / rev_backward (gridding_cuda.cpp:69-91,96-97;
+ *          gridding_reverse.cu:30-122, 124-236). grid[b,scale,scale,scale]. */
+int sn_gridding_reverse_forward(const float *grid, int b, int scale,
+                                float *ptcloud, void *stream);
+int sn_gridding_reverse_backward(const float *grad_ptcloud, const float *grid,
+                                 int b, int scale, float *grad_grid,
+                                 void *stream);
+
+/* --------------------------------------------------- cubic feature sampling
+ * replaces cubic_feature_sampling.forward / backward
+ *          (cuda/cubic_feature_sampling/cubic_feature_sampling_cuda.cpp:36-61;
+ *           cubic_feature_sampling.cu:29-133, 135-205).
+ * ptcloud[b,npts,3] in voxel space; feat[b,c,scale^3];
+ * out[b,npts,(2ns)^3,c]; idx[b,npts,(2ns)^3]; grad_feat fully overwritten. */
+int sn_cubic_forward(const float *ptcloud, const float *feat, int b, int npts,
+                     int c, int scale, int ns, float *out, int *idx,
+                     void *stream);
+int sn_cubic_backward(const float *grad_out, const int *idx, int b, int npts,
+                      int c, int scale, int ns, float *grad_feat,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPARENET_HIP_H */

@@ -1,0 +1,283 @@
+// chamfer.hip -- Chamfer distance forward / backward for MI355X (gfx950).
+//
+// Reference semantics: cuda/chamfer_distance/chamfer_distance.cu:7-137 (forward),
+// :159-209 (backward); CPU statement chamfer_distance.cpp:57-180.
+//   dist[b,j] = min_k d(j,k),  d = (dx*dx + dy*dy) + dz*dz with dx = t.x - q.x,
+//   three separately rounded products and two rounded sums (no FMA),
+//   idx[b,j]  = LOWEST k attaining the minimum.
+//
+// Design (wave64, fp32-VALU bound -- 9 flop/pair, O(N) bytes):
+//   * one lane owns QPL=4 queries in VGPRs, packed two-by-two so the distance
+//     arithmetic issues as v_pk_add_f32 / v_pk_mul_f32 (2 pairs per VALU slot);
+//   * targets stream through a 1024-point LDS tile laid out chunk-SoA
+//     (x[8] y[8] z[8] per chunk) and are read with wave-uniform ds_read_b128
+//     (broadcast, conflict free); the next tile's global loads are issued
+//     before the current tile is consumed;
+//   * arg-min is tracked per 8-target CHUNK: the chunk minimum is a v_min3_f32
+//     tree (0.5 op/pair) and only one compare + two selects per chunk touch the
+//     running (best, best_chunk).  Minimum is exact in fp32, so "first chunk
+//     whose minimum beats the running best with strict <" followed by "first k
+//     inside that chunk whose recomputed distance equals the minimum" is exactly
+//     "lowest k attaining the minimum";
+//   * both directions (1->2 and 2->1) run in ONE launch; blocks that share a
+//     target cloud are mapped to the same XCD (block id % 8) so the cloud's
+//     196 KB stay in one L2.
+#include "common.hpp"
+
+namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr int kThreads = 256;
+constexpr int kQPL = 4;                  // queries per lane
+constexpr int kQPB = kThreads * kQPL;    // queries per block
+constexpr int kChunk = 8;                // targets per arg-min chunk
+constexpr int kTile = 1024;              // targets per LDS tile
+constexpr int kTileF4 = kTile / kChunk * 6;  // float4 slots per tile
+
+__device__ __forceinline__ float min3(float a, float b, float c) {
+  return __builtin_fminf(__builtin_fminf(a, b), c);
+}
+
+// d = (dx*dx + dy*dy) + dz*dz, two queries at once, no contraction
+__device__ __forceinline__ f2 dist2(float tx, float ty, float tz, f2 qx, f2 qy, f2 qz) {
+#pragma clang fp contract(off)
+  const f2 dx = tx - qx;
+  const f2 dy = ty - qy;
+  const f2 dz = tz - qz;
+  const f2 xx = dx * dx;
+  const f2 yy = dy * dy;
+  const f2 zz = dz * dz;
+  const f2 s = xx + yy;
+  return s + zz;
+}
+
+__device__ __forceinline__ float dist1(float tx, float ty, float tz, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+  const float dx = tx - qx;
+  const float dy = ty - qy;
+  const float dz = tz - qz;
+  const float xx = dx * dx;
+  const float yy = dy * dy;
+  const float zz = dz * dz;
+  const float s = xx + yy;
+  return s + zz;
+}
+
+__global__ __launch_bounds__(kThreads) void chamfer_fwd_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, int B, int N, int M,
+    float *__restrict__ dist1_out, int *__restrict__ idx1_out,
+    float *__restrict__ dist2_out, int *__restrict__ idx2_out, int nb1, int nb2, int nb_max) {
+  __shared__ float4 tile[kTileF4];
+
+  // ---- XCD-aware decode: block g runs on XCD g%8; all blocks of one target
+  // cloud (b, direction) share that residue.
+  const int g = blockIdx.x;
+  const int xcd = g & 7;
+  const int r = g >> 3;
+  const int cloud = (r / nb_max) * 8 + xcd;
+  const int blk = r % nb_max;
+  if (cloud >= 2 * B) return;
+  const int b = cloud >> 1;
+  const int dir = cloud & 1;
+  if (blk >= (dir ? nb2 : nb1)) return;
+
+  const int nq = dir ? M : N;   // queries
+  const int nt = dir ? N : M;   // targets
+  const float *__restrict__ q = (dir ? xyz2 : xyz1) + (size_t)b * nq * 3;
+  const float *__restrict__ t = (dir ? xyz1 : xyz2) + (size_t)b * nt * 3;
+  float *__restrict__ dist_out = (dir ? dist2_out : dist1_out) + (size_t)b * nq;
+  int *__restrict__ idx_out = (dir ? idx2_out : idx1_out) + (size_t)b * nq;
+
+  const int tid = threadIdx.x;
+  const int q0 = blk * kQPB + tid;
+
+  f2 qx[kQPL / 2], qy[kQPL / 2], qz[kQPL / 2];
+#pragma unroll
+  for (int i = 0; i < kQPL; ++i) {
+    int j = q0 + i * kThreads;
+    j = j < nq ? j : nq - 1;
+    qx[i >> 1][i & 1] = q[j * 3 + 0];
+    qy[i >> 1][i & 1] = q[j * 3 + 1];
+    qz[i >> 1][i & 1] = q[j * 3 + 2];
+  }
+
+  float best[kQPL];
+  int bchunk[kQPL];
+#pragma unroll
+  for (int i = 0; i < kQPL; ++i) {
+    best[i] = __builtin_inff();
+    bchunk[i] = 0;
+  }
+
+  const int ntiles = sn::ceil_div(nt, kTile);
+  constexpr int kLd = kTile * 3 / kThreads;  // floats per thread per tile (12)
+  float stage[kLd];
+  const int nt3 = nt * 3;
+
+  auto load_stage = [&](int tile_id) {
+    const int base = tile_id * kTile * 3;
+#pragma unroll
+    for (int i = 0; i < kLd; ++i) {
+      const int e = base + i * kThreads + tid;
+      stage[i] = e < nt3 ? t[e] : __builtin_inff();
+    }
+  };
+  auto store_stage = [&]() {
+    float *lds = reinterpret_cast<float *>(tile);
+#pragma unroll
+    for (int i = 0; i < kLd; ++i) {
+      const int e = i * kThreads + tid;
+      const int k = e / 3, comp = e - k * 3;
+      lds[(k >> 3) * 24 + comp * 8 + (k & 7)] = stage[i];
+    }
+  };
+
+  load_stage(0);
+  for (int tile_id = 0; tile_id < ntiles; ++tile_id) {
+    __syncthreads();  // previous tile fully consumed
+    store_stage();
+    __syncthreads();
+    if (tile_id + 1 < ntiles) load_stage(tile_id + 1);
+
+    const int chunk0 = tile_id * (kTile / kChunk);
+    const int rem = nt - tile_id * kTile;
+    const int nchunks = rem >= kTile ? kTile / kChunk : sn::ceil_div(rem, kChunk);
+#pragma unroll 2
+    for (int c = 0; c < nchunks; ++c) {
+      const float4 xa = tile[c * 6 + 0], xb = tile[c * 6 + 1];
+      const float4 ya = tile[c * 6 + 2], yb = tile[c * 6 + 3];
+      const float4 za = tile[c * 6 + 4], zb = tile[c * 6 + 5];
+      const float tx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+      const float ty[8] = {ya.x, ya.y, ya.z, ya.w, yb.x, yb.y, yb.z, yb.w};
+      const float tz[8] = {za.x, za.y, za.z, za.w, zb.x, zb.y, zb.z, zb.w};
+#pragma unroll
+      for (int p = 0; p < kQPL / 2; ++p) {
+        f2 d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) d[k] = dist2(tx[k], ty[k], tz[k], qx[p], qy[p], qz[p]);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          float m = min3(d[0][h], d[1][h], d[2][h]);
+          m = min3(m, d[3][h], d[4][h]);
+          m = min3(m, d[5][h], d[6][h]);
+          m = __builtin_fminf(m, d[7][h]);
+          const int i = p * 2 + h;
+          const bool lt = m < best[i];
+          best[i] = lt ? m : best[i];
+          bchunk[i] = lt ? chunk0 + c : bchunk[i];
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: first k inside the winning chunk whose distance equals best
+#pragma unroll
+  for (int i = 0; i < kQPL; ++i) {
+    const int j = q0 + i * kThreads;
+    if (j >= nq) continue;
+    const float x = qx[i >> 1][i & 1], y = qy[i >> 1][i & 1], z = qz[i >> 1][i & 1];
+    const int k0 = bchunk[i] * kChunk;
+    int bi = k0;
+    bool found = false;
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+      const int kk = k0 + k < nt ? k0 + k : nt - 1;
+      const float d = dist1(t[kk * 3 + 0], t[kk * 3 + 1], t[kk * 3 + 2], x, y, z);
+      const bool hit = !found && (d == best[i]) && (k0 + k < nt);
+      bi = hit ? k0 + k : bi;
+      found = found || hit;
+    }
+    dist_out[j] = best[i];
+    idx_out[j] = bi;
+  }
+}
+
+// ---------------------------------------------------------------- backward
+// pass 1 (plain stores): own term  grad_a[j] = 2*gd[j] * (a[j] - b[idx[j]])
+__global__ __launch_bounds__(256) void chamfer_bwd_own_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ gd1, const float *__restrict__ gd2, const int *__restrict__ idx1,
+    const int *__restrict__ idx2, int B, int N, int M, float *__restrict__ g1,
+    float *__restrict__ g2) {
+  const long total1 = (long)B * N, total = total1 + (long)B * M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const bool second = e >= total1;
+    const long f = second ? e - total1 : e;
+    const int na = second ? M : N, nb = second ? N : M;
+    const int b = (int)(f / na);
+    const float *a = second ? xyz2 : xyz1;
+    const float *o = second ? xyz1 : xyz2;
+    const int k = (second ? idx2 : idx1)[f];
+    const float g = (second ? gd2 : gd1)[f] * 2;
+    const float *pa = a + f * 3;
+    const float *po = o + ((long)b * nb + k) * 3;
+    float *ga = (second ? g2 : g1) + f * 3;
+    ga[0] = g * (pa[0] - po[0]);
+    ga[1] = g * (pa[1] - po[1]);
+    ga[2] = g * (pa[2] - po[2]);
+  }
+}
+
+// pass 2 (fp32 atomics): scatter term  grad_b[idx[j]] -= 2*gd[j] * (a[j] - b[idx[j]])
+__global__ __launch_bounds__(256) void chamfer_bwd_scatter_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ gd1, const float *__restrict__ gd2, const int *__restrict__ idx1,
+    const int *__restrict__ idx2, int B, int N, int M, float *__restrict__ g1,
+    float *__restrict__ g2) {
+  const long total1 = (long)B * N, total = total1 + (long)B * M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const bool second = e >= total1;
+    const long f = second ? e - total1 : e;
+    const int na = second ? M : N, nb = second ? N : M;
+    const int b = (int)(f / na);
+    const float *a = second ? xyz2 : xyz1;
+    const float *o = second ? xyz1 : xyz2;
+    const int k = (second ? idx2 : idx1)[f];
+    const float g = (second ? gd2 : gd1)[f] * 2;
+    const float *pa = a + f * 3;
+    const long ob = ((long)b * nb + k) * 3;
+    const float *po = o + ob;
+    float *go = (second ? g1 : g2) + ob;
+    unsafeAtomicAdd(go + 0, -(g * (pa[0] - po[0])));
+    unsafeAtomicAdd(go + 1, -(g * (pa[1] - po[1])));
+    unsafeAtomicAdd(go + 2, -(g * (pa[2] - po[2])));
+  }
+}
+
+}  // namespace
+
+extern "C" int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n, int m,
+                                  float *dist1, int *idx1, float *dist2, int *idx2,
+                                  void *stream) {
+  SN_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2, "sn_chamfer_forward: null pointer");
+  SN_REQUIRE(b >= 1 && n >= 1 && m >= 1, "sn_chamfer_forward: need b,n,m >= 1 (got %d,%d,%d)", b, n, m);
+  SN_REQUIRE((long)b * n < (1L << 29) && (long)b * m < (1L << 29), "sn_chamfer_forward: too large");
+  const int nb1 = sn::ceil_div(n, kQPB), nb2 = sn::ceil_div(m, kQPB);
+  const int nb_max = nb1 > nb2 ? nb1 : nb2;
+  const int clouds_per_xcd = sn::ceil_div(2 * b, 8);
+  const int grid = 8 * clouds_per_xcd * nb_max;
+  chamfer_fwd_kernel<<<grid, kThreads, 0, sn::as_stream(stream)>>>(
+      xyz1, xyz2, b, n, m, dist1, idx1, dist2, idx2, nb1, nb2, nb_max);
+  return sn::launch_status("sn_chamfer_forward");
+}
+
+extern "C" int sn_chamfer_backward(const float *xyz1, const float *xyz2, const float *graddist1,
+                                   const float *graddist2, const int *idx1, const int *idx2,
+                                   int b, int n, int m, float *gradxyz1, float *gradxyz2,
+                                   void *stream) {
+  SN_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2,
+             "sn_chamfer_backward: null pointer");
+  SN_REQUIRE(b >= 1 && n >= 1 && m >= 1, "sn_chamfer_backward: need b,n,m >= 1");
+  const long total = (long)b * n + (long)b * m;
+  long blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipStream_t s = sn::as_stream(stream);
+  chamfer_bwd_own_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1, idx2,
+                                                      b, n, m, gradxyz1, gradxyz2);
+  chamfer_bwd_scatter_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1,
+                                                          idx2, b, n, m, gradxyz1, gradxyz2);
+  return sn::launch_status("sn_chamfer_backward");
+}
