@@ -87,11 +87,15 @@ int sn_emd_backward(const float *xyz1, const float *xyz2,
  *          neighbor/cost scratch tensors
  *          (expansion_penalty_module.py:33-34).
  * primitive_size: power of two, 2..512, n % primitive_size == 0.
- * mean_mst_length[b] is returned ALREADY divided by n/primitive_size
- * (expansion_penalty_module.py:40 does that division in Python). */
+ * mean_mst_length[b] = sum over patches (ascending patch order) of the patch's
+ * mean MST edge length, UN-normalised exactly like the reference kernel leaves
+ * it; expansion_penalty_module.py:40 divides by n/primitive_size in Python and
+ * the host mirror does the same. */
+size_t sn_expansion_workspace_bytes(int b, int n, int primitive_size);
 int sn_expansion_forward(const float *xyz, int b, int n, int primitive_size,
                          float alpha, float *dist, int *assignment,
-                         float *mean_mst_length, void *stream);
+                         float *mean_mst_length, void *workspace,
+                         size_t workspace_bytes, void *stream);
 /* replaces expansion_penalty.backward (expansion_penalty.cpp:14-17,21;
  *          expansion_penalty_cuda.cu:167-198); gradxyz fully overwritten. */
 int sn_expansion_backward(const float *xyz, const float *graddist,

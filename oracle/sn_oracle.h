@@ -55,8 +55,9 @@ void oracle_emd_backward(const float *xyz1, const float *xyz2,
                          int n, float *gradxyz1);
 
 /* ---- Expansion penalty: cuda/expansion_penalty/expansion_penalty_cuda.cu:7-149
- * mean_mst_length is returned already divided by (n/primitive_size), as the
- * Python module does (expansion_penalty_module.py:40). */
+ * mean_mst_length[b] = sum over patches of the patch's mean MST edge length,
+ * UN-normalised like the kernel leaves it; the Python module divides by
+ * n/primitive_size afterwards (expansion_penalty_module.py:40). */
 void oracle_expansion_forward(const float *xyz, int b, int n,
                               int primitive_size, float alpha, float *dist,
                               int *assignment, float *mean_mst_length);
