@@ -46,7 +46,7 @@ __device__ __forceinline__ float bid_value(float tx, float ty, float tz, float p
   const float dx = tx - x1, dy = ty - y1, dz = tz - z1;
   const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
   const float s = (xx + yy) + zz;
-  return (float)((3.0 - (double)__fsqrt_rn(s)) - (double)p);
+  return (float)((3.0 - (double)__builtin_sqrtf(s)) - (double)p);
 }
 
 __device__ __forceinline__ void top2_push(Top2 &t, float d, int k) {

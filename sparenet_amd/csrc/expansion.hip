@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void expansion_fwd_kernel(
       float cand = 1e9f;
       if (!((vis >> r) & 1u)) {
         const float dx = px[r] - ql.x, dy = py[r] - ql.y, dz = pz[r] - ql.z;
-        const float d = __fsqrt_rn((dx * dx + dy * dy) + dz * dz);
+        const float d = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
         if (d < cur_dis[r]) {
           cur_dis[r] = d;
           cur_idx[r] = last;

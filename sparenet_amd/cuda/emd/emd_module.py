@@ -20,7 +20,7 @@ from torch.autograd import Function
 from sparenet_amd import _lib
 
 
-def emd_forward_raw(xyz1, xyz2, eps, iters, stats=None):
+def emd_forward_raw(xyz1, xyz2, eps, iters, stats=None, return_workspace=False):
     """C-ABI call on contiguous fp32 CUDA tensors; returns (dist, assignment).
     stats: optional int64[2] CUDA tensor accumulating (effective pairs, active iterations)."""
     batchsize, n, _ = xyz1.size()
@@ -36,6 +36,8 @@ def emd_forward_raw(xyz1, xyz2, eps, iters, stats=None):
             int(iters), _lib.fptr(dist, "dist"), _lib.iptr(assignment, "assignment"),
             ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), sp, _lib.stream_of(xyz1))
     _lib.check(code, "sn_emd_forward")
+    if return_workspace:
+        return dist, assignment, ws
     return dist, assignment
 
 

@@ -130,6 +130,25 @@ def test_hip_matches_oracle(b, n, iters, eps, kind, seed, dev):
 
 
 @pytest.mark.gpu
+def test_hip_prices_bit_exact_when_converged(dev):
+    """Sensitive arithmetic check: when the auction converges before the last
+    iteration (no forced assignment, hence no price race), the price vector --
+    an accumulation of every winning bid increment, i.e. of sqrtf, the double
+    detour and the top-2 logic -- must equal the oracle's bit for bit."""
+    from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
+
+    x, y = _clouds(2, 2048, 12, "near")
+    d0, a0, aux = oracle.emd_forward(x, y, 0.005, 30, mt=True, return_aux=True)
+    assert aux["unass"][-1] == 0, "pick a case that converges"
+    d, a, ws = emd_forward_raw(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), 0.005, 30,
+                               return_workspace=True)
+    arr = (2 * 2048 * 4 + 255) // 256 * 256
+    price = ws[arr:arr + 2 * 2048 * 4].view(torch.float32).view(2, 2048).cpu().numpy()
+    assert np.array_equal(a.cpu().numpy(), a0)
+    assert np.array_equal(price, aux["price"])
+
+
+@pytest.mark.gpu
 def test_hip_autograd_and_module_api(dev):
     from sparenet_amd.cuda.emd.emd_module import emdModule
 

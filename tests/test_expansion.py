@@ -62,6 +62,17 @@ def test_oracle_backward_formula():
     np.testing.assert_array_equal(g, ref)
 
 
+def _check_mean(m, m0_sum, n, P):
+    # the host mirror divides by n/P with the same torch op as the reference module (:40);
+    # torch evaluates tensor/scalar on the GPU as tensor * (1/scalar): exact for 2^k patches
+    m = m.detach().cpu().numpy()
+    np_ = n // P
+    if np_ & (np_ - 1) == 0:
+        assert np.array_equal(m, (m0_sum / np.float32(np_)).astype(np.float32))
+    else:
+        np.testing.assert_allclose(m, m0_sum / np.float32(np_), rtol=2e-7)
+
+
 def _hip(x, P, alpha, dev):
     from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyFunction
 
@@ -79,7 +90,7 @@ def test_hip_matches_golden(golden_dir, dev):
         assert np.array_equal(a.cpu().numpy(), z["assignment"]), f
         assert np.array_equal(d.detach().cpu().numpy(), z["dist"]), f
         np_ = z["xyz"].shape[1] / P
-        assert np.array_equal(m.cpu().numpy(), (z["mean_mst_sum"] / np.float32(np_)).astype(np.float32)), f
+        assert np.array_equal(m.detach().cpu().numpy(), (z["mean_mst_sum"] / np.float32(np_)).astype(np.float32)), f
 
 
 @pytest.mark.gpu
@@ -98,7 +109,7 @@ def test_hip_matches_oracle(b, n, P, alpha, kind, dev):
     xt, d, a, m = _hip(x, P, alpha, dev)
     assert np.array_equal(a.cpu().numpy(), a0)
     assert np.array_equal(d.detach().cpu().numpy(), d0)
-    assert np.array_equal(m.cpu().numpy(), (m0 / np.float32(n / P)).astype(np.float32))
+    _check_mean(m, m0, n, P)
     gd = rng.random((b, n), dtype=np.float32)
     (d * torch.from_numpy(gd).to(dev)).sum().backward()
     np.testing.assert_array_equal(xt.grad.cpu().numpy(), oracle.expansion_backward(x, gd, a0))
@@ -111,7 +122,7 @@ def test_hip_full_size(dev):
     g = torch.Generator().manual_seed(1234)
     x = torch.rand(32, 16384, 3, generator=g)
     _, d, a, m = _hip(x.numpy(), 512, 1.5, dev)
-    d, a, m = d.detach().cpu().numpy(), a.cpu().numpy(), m.cpu().numpy()
+    d, a, m = d.detach().cpu().numpy(), a.cpu().numpy(), m.detach().cpu().numpy()
     sel = [0, 7, 16, 31]
     d0, a0, m0 = oracle.expansion_forward(x[sel].numpy(), 512, 1.5)
     assert np.array_equal(a[sel], a0) and np.array_equal(d[sel], d0)
