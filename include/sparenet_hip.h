@@ -150,23 +150,6 @@ int sn_p2i_sum_backward(const float *out_grad, const float *points,
                         int channels, int batch, int h, int w, float radius,
                         float *points_grad, float *feat_grad, void *stream);
 
-/* ------------------------------------------------- fused depth-map renderer
- * replaces the tensor program of ComputeDepthMaps.forward
- *          (utils/p2i_utils.py:211-252: transform :153-165, depth feature
- *          :226-228, one p2i(max) per radius :230-251) for one view.
- * data[b,n,3]; pre_matrix[16] row-major 4x4 (host pointer, proj @ view);
- * zrange[2] device pointer = (min z, max z) over the transformed input,
- * produced by sn_depth_zrange; out[b, nradius, s, s]; out_ids likewise.
- * background is zero (p2i_utils.py:236-241). */
-size_t sn_depthmaps_workspace_bytes(int b, int nradius, int s);
-int sn_depth_zrange(const float *data, int b, int n, const float *pre_matrix,
-                    float *zrange, void *stream);
-int sn_depthmaps_forward(const float *data, int b, int n,
-                         const float *pre_matrix, const float *zrange,
-                         const float *radius_list, int nradius, int s,
-                         float *out, int *out_ids, void *workspace,
-                         size_t workspace_bytes, void *stream);
-
 /* ----------------------------------------------------------------- gridding
  * replaces gridding.forward / backward (cuda/gridding/gridding_cuda.cpp:44-67,
  *          94-95; gridding.cu:29-211, 213-335).  ptcloud[b,npts,3] already

@@ -1,0 +1,144 @@
+"""Differentiable multi-view depth-map rendering of point clouds.
+
+Host-side mirror of the reference's utils/p2i_utils.py: ComputeDepthMaps (:168-252)
+with the same constructor / forward signature, N_VIEWS_PREDEFINED (:9) and the camera
+helpers look_at (:16-82), perspective (:85-121), orthorgonal (:124-150), transform
+(:153-165).  The splat itself is the HIP p2i op (sparenet_amd.cuda.p2i_op).
+
+What forward() computes, per view (reference :211-252):
+    pos      = (P @ V) [x y z 1]^T, divided by w
+    (i, j)   = (-pos.y, pos.x)                      image row / column in [-1, 1]
+    feature  = 1 - (pos.z - min z) / (max z - min z)   min/max over the WHOLE input tensor
+    map_r    = p2i(ij, feature, reduce="max", kernel_radius=r) on a zero background
+    output   = cat_r map_r  -> [B, len(radius_list), S, S]
+The camera matrices are evaluated with the same fp32 torch operations as the reference
+so the eight P@V matrices agree bit for bit (tests/golden/depthmaps_*.npz); the
+per-point transform is a [B*N,3]x[3,4] product instead of B*N expanded 4x4 bmm's.
+"""
+import math
+
+import torch
+
+from sparenet_amd.cuda.p2i_op import p2i
+
+N_VIEWS_PREDEFINED = 8
+
+_EYES = [(sx, sy, sz) for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)]
+
+
+def normalize(x, dim):
+    floor = torch.tensor(1e-6, dtype=x.dtype, device=x.device)
+    return x / torch.max(x.norm(None, dim=dim, keepdim=True), floor)
+
+
+def _rows_to_mat(rows):
+    """rows: 16 tensors of shape [batch] -> [batch, 4, 4]."""
+    return torch.stack(rows, -1).view(-1, 4, 4)
+
+
+def look_at(eyes, centers, ups):
+    """View matrix [batch,4,4] of an observer at `eyes` looking at `centers` with head
+    direction `ups` (all [batch,3]): translate the eye to the origin, then rotate the
+    observer's right / up / backward axes onto x / y / z."""
+    back = normalize(eyes - centers, dim=1)
+    right = normalize(torch.cross(ups, back, dim=1), dim=1)
+    up = torch.cross(back, right, dim=1)
+    o = torch.zeros([eyes.size(0)], dtype=eyes.dtype, device=eyes.device)
+    i = torch.ones([eyes.size(0)], dtype=eyes.dtype, device=eyes.device)
+    shift = _rows_to_mat([i, o, o, -eyes[:, 0],
+                          o, i, o, -eyes[:, 1],
+                          o, o, i, -eyes[:, 2],
+                          o, o, o, i])
+    turn = _rows_to_mat([right[:, 0], right[:, 1], right[:, 2], o,
+                         up[:, 0], up[:, 1], up[:, 2], o,
+                         back[:, 0], back[:, 1], back[:, 2], o,
+                         o, o, o, i])
+    return turn @ shift
+
+
+def perspective(fovy, aspect, z_near, z_far):
+    """Right-handed perspective projection [batch,4,4]; all arguments are [batch]."""
+    t = torch.tan(fovy / 2.0)
+    o = torch.zeros_like(fovy)
+    i = torch.ones_like(fovy)
+    k1 = -(z_far + z_near) / (z_far - z_near)
+    k2 = -2.0 * z_far * z_near / (z_far - z_near)
+    return _rows_to_mat([1.0 / aspect / t, o, o, o,
+                         o, 1.0 / t, o, o,
+                         o, o, k1, k2,
+                         o, o, -i, o])
+
+
+def orthorgonal(scalex, scaley, z_near, z_far):
+    """Orthographic projection [batch,4,4] (the reference's spelling is kept)."""
+    o = torch.zeros_like(z_near)
+    i = torch.ones_like(z_near)
+    k1 = -2.0 / (z_far - z_near)
+    k2 = (z_far + z_near) / (z_far - z_near)
+    return _rows_to_mat([scalex, o, o, o,
+                         o, scaley, o, o,
+                         o, o, k1, k2,
+                         o, o, o, i])
+
+
+def transform(matrix, points):
+    """matrix [4,4] or [npoints,4,4], points [npoints,3] -> projected [npoints,3]."""
+    if matrix.dim() == 3:
+        hom = torch.cat([points, torch.ones_like(points[:, :1])], dim=1).unsqueeze(-1)
+        out = (matrix @ hom).squeeze(-1)
+    else:
+        out = points @ matrix[:, :3].t() + matrix[:, 3]
+    return out[:, :3] / out[:, 3:4]
+
+
+class ComputeDepthMaps(torch.nn.Module):
+    def __init__(self, projection: str = "orthorgonal", eyepos_scale: float = 1.0,
+                 image_size: int = 256):
+        super().__init__()
+        assert projection in {"perspective", "orthorgonal"}
+        self.image_size = image_size
+        self.eyes_pos_list = [list(e) for e in _EYES]
+        self.num_views = len(self.eyes_pos_list)
+        f32 = dict(dtype=torch.float32)
+        if projection == "perspective":
+            self.projection_matrix = perspective(
+                fovy=torch.tensor([math.pi / 4], **f32), aspect=torch.tensor([1.0], **f32),
+                z_near=torch.tensor([0.1], **f32), z_far=torch.tensor([10.0], **f32))
+        else:
+            self.projection_matrix = orthorgonal(
+                scalex=torch.tensor([1.5], **f32), scaley=torch.tensor([1.5], **f32),
+                z_near=torch.tensor([0.1], **f32), z_far=torch.tensor([10.0], **f32))
+        mats = []
+        for eye in self.eyes_pos_list:
+            view = look_at(eyes=torch.tensor([eye], **f32) * eyepos_scale,
+                           centers=torch.tensor([[0, 0, 0]], **f32),
+                           ups=torch.tensor([[0, 0, 1]], **f32))
+            mats.append((self.projection_matrix @ view)[0])
+        # [8,4,4]; a real buffer, so .to(device) moves all views once (the reference keeps a
+        # Python list of CPU matrices and copies one to the device on every call, :208,:217)
+        self.register_buffer("pre_matrices", torch.stack(mats), persistent=False)
+        self.pre_matrix_list = [m.unsqueeze(0) for m in mats]
+
+    def project(self, data, view_id):
+        """data [B,N,3] -> (pos_ijs [B*N,2], point_features [B*N,1]) exactly as the reference
+        builds them before calling p2i."""
+        m = self.pre_matrices[view_id].to(device=data.device, dtype=data.dtype)
+        pos = transform(m, data.reshape(-1, 3))
+        pos_ijs = torch.stack([-pos[:, 1], pos[:, 0]], dim=1)
+        z = pos[:, 2:3]
+        zmin, zmax = z.min(), z.max()
+        point_features = 1.0 - (z - zmin) / (zmax - zmin)
+        return pos_ijs, point_features
+
+    def forward(self, data, view_id=0, radius_list=[10.0]):
+        if view_id >= self.num_views:
+            return None
+        batch, npoints = data.size(0), data.size(1)
+        pos_ijs, point_features = self.project(data, view_id)
+        background = torch.zeros(batch, 1, self.image_size, self.image_size, dtype=data.dtype,
+                                 device=data.device)
+        batch_inds = torch.arange(batch, dtype=torch.int32, device=data.device)
+        batch_inds = batch_inds.repeat_interleave(npoints)
+        maps = [p2i(pos_ijs, point_features, batch_inds, background, kernel_radius=r,
+                    kernel_kind_str="cos", reduce="max") for r in radius_list]
+        return maps[0] if len(maps) == 1 else torch.cat(maps, dim=1)
