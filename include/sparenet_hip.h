@@ -104,10 +104,13 @@ int sn_expansion_backward(const float *xyz, const float *graddist,
 
 /* ---------------------------------------------------------------------- MDS
  * replaces MDS.minimum_density_sampling (cuda/MDS/MDS.cpp:114-135,140;
- *          kernel MDS_cuda.cu:91-268); the `temp` tensor MDS.cpp:119-121
- *          allocates lives on-chip.  idx[b,m] int32. */
+ *          kernel MDS_cuda.cu:91-268).  idx[b,m] int32, m <= n.
+ * The `temp` tensor MDS.cpp:119-121 allocates lives in registers; only clouds
+ * with more than 24576 points need `workspace` (sn_mds_workspace_bytes() > 0).
+ * The density kernel is sn_expf (include/sn_expf.h), not libm/OCML expf. */
+size_t sn_mds_workspace_bytes(int b, int n);
 int sn_mds(const float *xyz, int b, int n, int m, const float *mean_mst_length,
-           int *idx, void *stream);
+           int *idx, void *workspace, size_t workspace_bytes, void *stream);
 /* replaces MDS.gather_forward / MDS.gather_backward (MDS.cpp:54-113,138-139;
  *          kernels MDS_cuda.cu:29-79). feat[b,c,n], idx[b,m], out[b,c,m].
  * grad_feat is fully overwritten. */

@@ -140,12 +140,12 @@ def expansion_backward(xyz, graddist, assignment):
 
 
 # ------------------------------------------------------------------------- mds
-def mds(xyz, npoint, mean_mst_length, exp_mode=1):
+def mds(xyz, npoint, mean_mst_length, exp_mode=1, bs_override=0):
     xyz, p = _f(xyz)
     mml, pm = _f(mean_mst_length)
     b, n, _ = xyz.shape
     idx = np.zeros((b, npoint), np.int32)
-    lib().oracle_mds(p, b, n, int(npoint), pm, int(exp_mode), _pi(idx))
+    lib().oracle_mds(p, b, n, int(npoint), pm, int(exp_mode), int(bs_override), _pi(idx))
     return idx
 
 

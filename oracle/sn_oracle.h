@@ -68,9 +68,11 @@ void oracle_expansion_backward(const float *xyz, const float *graddist,
 
 /* ---- MDS: cuda/MDS/MDS_cuda.cu:91-211 (intended, race-free semantics) ----
  * exp_mode 0: libm expf (what the reference source says, not bit-portable)
- * exp_mode 1: sn_expf polynomial shared verbatim with the HIP kernel */
+ * exp_mode 1: sn_expf polynomial shared verbatim with the HIP kernel
+ * bs_override > 0 replaces the reference's thread count (tie order only) */
 void oracle_mds(const float *xyz, int b, int n, int m,
-                const float *mean_mst_length, int exp_mode, int *idx);
+                const float *mean_mst_length, int exp_mode, int bs_override,
+                int *idx);
 /* MDS_cuda.cu:29-41 / :55-69 */
 void oracle_gather_forward(const float *feat, const int *idx, int b, int c,
                            int n, int m, float *out);

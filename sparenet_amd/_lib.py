@@ -31,7 +31,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sn_last_error.restype = ctypes.c_char_p
         for name in ("sn_emd_workspace_bytes", "sn_p2i_max_workspace_bytes",
-                     "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes"):
+                     "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes", "sn_mds_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_size_t
     return _lib

@@ -143,7 +143,39 @@ def gen_expansion():
             provenance=np.array("reference expansion_penalty_cuda.cu:7-149 kernel text under tests/golden/gen/simt.h"))
 
 
-GENS = {"emd": gen_emd, "expansion": gen_expansion}
+# ------------------------------------------------------------------------ MDS
+def gen_mds():
+    import oracle
+
+    inc = extract("cuda/MDS/MDS_cuda.cu", 81, 211, "mds_kernels.inc")
+    exe = compile_harness("emu_mds.cpp", inc, "emu_mds")
+    cases = [
+        ("mds_2x300_m128", 2, 300, 128, 0.05, 0),
+        ("mds_1x9000_m600", 1, 9000, 600, 0.012, 1),     # exercises the k >= 8192 x2 branch
+        ("mds_1x19384_m1024", 1, 19384, 1024, 0.008, 2),  # SpareNet shape (prefix of the m=16384 run)
+        ("mds_3x64_m64", 3, 64, 64, 0.2, 3),              # m == n: every point selected
+    ]
+    for name, b, n, m, mml, seed in cases:
+        g = torch.Generator().manual_seed(seed)
+        x = torch.rand(b, n, 3, generator=g).numpy()
+        mm = (mml * (1 + 0.1 * torch.rand(b, generator=g))).numpy().astype(np.float32)
+        raw = run(exe, struct.pack("iii", b, n, m), [mm, x])
+        idx = np.frombuffer(raw, np.int32, b * m).reshape(b, m)
+        oi = oracle.mds(x, m, mm, exp_mode=0, bs_override=1)
+        agree = np.array_equal(oi, idx)
+        print(f"{name}: emulated kernel<1> vs oracle(libm expf, bs=1) agree={agree} "
+              f"unique={all(len(set(r)) == m for r in idx)}")
+        if not agree:
+            print("   NOT stored -- investigate")
+            continue
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"), xyz=x, mean_mst_length=mm, npoint=np.int32(m),
+            idx_bs1=idx,
+            provenance=np.array("reference MDS_cuda.cu:81-211 minimum_density_sampling_kernel<1>, one "
+                                "thread, under tests/golden/gen/simt.h; exp(float) -> expf"))
+
+
+GENS = {"emd": gen_emd, "expansion": gen_expansion, "mds": gen_mds}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)
