@@ -169,9 +169,11 @@ int sn_gridding_backward(const float *grad_grid, const float *weights,
  *          gridding_reverse.cu:30-122, 124-236). grid[b,scale,scale,scale]. */
 int sn_gridding_reverse_forward(const float *grid, int b, int scale,
                                 float *ptcloud, void *stream);
+/* ptcloud = the raw rev_forward output (what GriddingReverseFunction saves,
+ * cuda/gridding/__init__.py:55), not the module's rescaled one. */
 int sn_gridding_reverse_backward(const float *grad_ptcloud, const float *grid,
-                                 int b, int scale, float *grad_grid,
-                                 void *stream);
+                                 const float *ptcloud, int b, int scale,
+                                 float *grad_grid, void *stream);
 
 /* --------------------------------------------------- cubic feature sampling
  * replaces cubic_feature_sampling.forward / backward

@@ -253,12 +253,14 @@ def gridding_reverse_forward(grid, scale):
     return out
 
 
-def gridding_reverse_backward(grad_ptcloud, grid, scale):
+def gridding_reverse_backward(grad_ptcloud, grid, ptcloud, scale):
+    """ptcloud = raw forward output (before the module's / scale * 2)."""
     gp, pgp = _f(grad_ptcloud)
     g, pg = _f(grid)
+    pc, ppc = _f(ptcloud)
     b = g.shape[0]
     out = np.zeros((b, scale, scale, scale), np.float32)
-    lib().oracle_gridding_reverse_backward(pgp, pg, b, int(scale), _pf(out))
+    lib().oracle_gridding_reverse_backward(pgp, pg, ppc, b, int(scale), _pf(out))
     return out
 
 

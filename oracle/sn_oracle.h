@@ -112,8 +112,8 @@ void oracle_gridding_backward(const float *grad_grid, const float *weights,
 void oracle_gridding_reverse_forward(const float *grid, int b, int scale,
                                      float *ptcloud);
 void oracle_gridding_reverse_backward(const float *grad_ptcloud,
-                                      const float *grid, int b, int scale,
-                                      float *grad_grid);
+                                      const float *grid, const float *ptcloud,
+                                      int b, int scale, float *grad_grid);
 void oracle_cubic_forward(const float *ptcloud, const float *feat, int b,
                           int npts, int c, int scale, int ns, float *out,
                           int *idx);

@@ -47,7 +47,9 @@ def extract(relpath, first, last, name, drop_prefixes=()):
 
 def compile_harness(src, inc, exe):
     exe = os.path.join(TMP, exe)
-    cmd = ["g++", "-std=c++20", "-O2", "-pthread", "-w", f'-DREF_KERNELS_INC="{inc}"',
+    defs = [f'-DREF_KERNELS_INC="{inc}"'] if isinstance(inc, str) else \
+        [f'-D{k}="{v}"' for k, v in inc.items()]
+    cmd = ["g++", "-std=c++20", "-O2", "-pthread", "-w", *defs,
            "-I", GEN, os.path.join(GEN, src), "-o", exe]
     subprocess.check_call(cmd)
     return exe
@@ -175,7 +177,100 @@ def gen_mds():
                                 "thread, under tests/golden/gen/simt.h; exp(float) -> expf"))
 
 
-GENS = {"emd": gen_emd, "expansion": gen_expansion, "mds": gen_mds}
+# ------------------------------------------------------------ gridding / cubic
+def gen_gridding():
+    import oracle
+
+    g = "cuda/gridding/gridding.cu"
+    r = "cuda/gridding/gridding_reverse.cu"
+    exe = compile_harness("emu_gridding.cpp", {
+        "REF_GRIDDING_INC": extract(g, 22, 177, "gridding_fwd.inc"),
+        "REF_GRIDDING_GRAD_INC": extract(g, 213, 312, "gridding_bwd.inc"),
+        "REF_REVERSE_INC": extract(r, 23, 103, "reverse_fwd.inc"),
+        "REF_REVERSE_GRAD_INC": extract(r, 124, 214, "reverse_bwd.inc")}, "emu_gridding")
+    for name, b, npts, scale, seed in [("gridding_2x300_s8", 2, 300, 8, 0), ("gridding_1x500_s16", 1, 500, 16, 1)]:
+        gen = torch.Generator().manual_seed(seed)
+        s = scale // 2
+        # points in [-0.95, 0.95): scaled coordinates stay inside the grid (cf. datasets/io.py:64-65)
+        pt = ((torch.rand(b, npts, 3, generator=gen) * 1.9 - 0.95) * s)
+        pt[:, ::17] = torch.round(pt[:, ::17])          # integer coordinates: lower == upper branch
+        pt = pt.clamp(-s, s - 1.001).numpy().astype(np.float32)
+        nv, n3 = (2 * s) ** 3, scale ** 3
+        gg = torch.rand(b, nv, generator=gen).numpy()
+        rgrid = (torch.rand(b, n3, generator=gen) * (torch.rand(b, n3, generator=gen) > 0.5)).numpy()
+        rgp = torch.rand(b, n3, 3, generator=gen).numpy()
+        raw = run(exe, struct.pack("iii", b, npts, scale), [pt, gg, rgrid, rgp])
+        o = 0
+
+        def take(dtype, shape):
+            nonlocal o
+            cnt = int(np.prod(shape))
+            a = np.frombuffer(raw, dtype, cnt, o).reshape(shape)
+            o += 4 * cnt
+            return a
+
+        grid = take(np.float32, (b, nv)); w = take(np.float32, (b, npts, 8, 3))
+        ix = take(np.int32, (b, npts, 8)); gpt = take(np.float32, (b, npts, 3))
+        rpt = take(np.float32, (b, n3, 3)); rgg = take(np.float32, (b, n3))
+        og, ow, oi = oracle.gridding_forward(pt, scale)
+        ogp = oracle.gridding_backward(gg, w, ix)
+        orp = oracle.gridding_reverse_forward(rgrid, scale)
+        org = oracle.gridding_reverse_backward(rgp, rgrid, rpt, scale)
+        exact = np.array_equal(ow, w) and np.array_equal(oi, ix) and np.array_equal(ogp, gpt) \
+            and np.array_equal(orp, rpt)
+        close = np.allclose(og, grid, rtol=1e-5, atol=1e-6) and \
+            np.allclose(org.reshape(b, -1), rgg, rtol=1e-4, atol=1e-5)
+        print(f"{name}: single-writer outputs exact={exact}, atomic sums close={close}, "
+              f"sum weights={grid.sum():.3f} (npts*b={npts * b})")
+        if not (exact and close):
+            print("   NOT stored -- investigate")
+            continue
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ptcloud=pt, scale=np.int32(scale),
+                            grad_grid=gg, grid=grid, weights=w, indexes=ix, grad_ptcloud=gpt,
+                            rev_grid=rgrid, rev_grad_ptcloud=rgp, rev_ptcloud=rpt, rev_grad_grid=rgg,
+                            provenance=np.array("reference gridding.cu / gridding_reverse.cu kernel text "
+                                                "under tests/golden/gen/simt.h"))
+
+
+def gen_cubic():
+    import oracle
+
+    cfile = "cuda/cubic_feature_sampling/cubic_feature_sampling.cu"
+    exe = compile_harness("emu_cubic.cpp", {
+        "REF_CUBIC_INC": extract(cfile, 22, 102, "cubic_fwd.inc"),
+        "REF_CUBIC_GRAD_INC": extract(cfile, 135, 174, "cubic_bwd.inc")}, "emu_cubic")
+    for name, b, npts, c, scale, ns, seed in [("cubic_2x200_c3_s8_ns1", 2, 200, 3, 8, 1, 0),
+                                             ("cubic_1x100_c2_s8_ns2", 1, 100, 2, 8, 2, 1)]:
+        gen = torch.Generator().manual_seed(seed)
+        h = scale / 2
+        pt = ((torch.rand(b, npts, 3, generator=gen) * 2.2 - 1.1) * h + h)   # some points off the grid
+        pt[:, ::13] = torch.round(pt[:, ::13])
+        pt = pt.numpy().astype(np.float32)
+        feat = torch.rand(b, c, scale, scale, scale, generator=gen).numpy()
+        nv = (2 * ns) ** 3
+        go = torch.rand(b, npts, nv, c, generator=gen).numpy()
+        raw = run(exe, struct.pack("iiiii", b, npts, c, scale, ns), [pt, feat, go])
+        o = 0
+        out = np.frombuffer(raw, np.float32, b * npts * nv * c, o).reshape(b, npts, nv, c); o += out.size * 4
+        ix = np.frombuffer(raw, np.int32, b * npts * nv, o).reshape(b, npts, nv); o += ix.size * 4
+        gf = np.frombuffer(raw, np.float32, b * c * scale ** 3, o).reshape(b, c, scale, scale, scale)
+        oo, oi = oracle.cubic_forward(pt, feat, ns)
+        ogf = oracle.cubic_backward(go, ix, c, scale, ns)
+        exact = np.array_equal(oo, out) and np.array_equal(oi, ix)
+        close = np.allclose(ogf, gf, rtol=1e-5, atol=1e-6)
+        print(f"{name}: fwd exact={exact} bwd close={close} off-grid slots={(ix < 0).mean():.2f}")
+        if not (exact and close):
+            print("   NOT stored -- investigate")
+            continue
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ptcloud=pt, feat=feat,
+                            neighborhood_size=np.int32(ns), grad_out=go, out=out, indexes=ix,
+                            grad_feat=gf,
+                            provenance=np.array("reference cubic_feature_sampling.cu kernel text under "
+                                                "tests/golden/gen/simt.h"))
+
+
+GENS = {"emd": gen_emd, "expansion": gen_expansion, "mds": gen_mds, "gridding": gen_gridding,
+        "cubic": gen_cubic}
 
 if __name__ == "__main__":
     which = sys.argv[1:] or list(GENS)

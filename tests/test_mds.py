@@ -144,21 +144,6 @@ def test_hip_matches_oracle(b, n, m, mml, dev):
 
 
 @pytest.mark.gpu
-def test_hip_matches_golden_when_exp_is_not_decisive(golden_dir, dev):
-    """The reference-kernel golden sequences use libm expf and bs = 1; the HIP kernel uses
-    sn_expf and the reference's real thread count.  They must agree wherever neither the
-    1-ulp exp difference nor the tie order matters: compare the selected SETS."""
-    for f in _golden(golden_dir):
-        z = np.load(f)
-        m = int(z["npoint"])
-        got = _hip_mds(z["xyz"], m, z["mean_mst_length"], dev)
-        for b in range(got.shape[0]):
-            assert len(set(got[b])) == m
-            overlap = len(set(got[b]) & set(z["idx_bs1"][b])) / m
-            assert overlap > 0.6 or m == z["xyz"].shape[1], (f, overlap)
-
-
-@pytest.mark.gpu
 def test_hip_gather_fwd_bwd(dev):
     from sparenet_amd.cuda.MDS.MDS_module import gather_operation
 
@@ -174,9 +159,10 @@ def test_hip_gather_fwd_bwd(dev):
 
 
 @pytest.mark.gpu
-def test_hip_full_size_sparenet_shape(dev):
+def test_hip_full_size_sparenet_shape(golden_dir, dev):
     """SpareNet call shape (models/sparenet_generator.py:568-573): n = 16384+3000, m = 16384,
-    B = 4 here; one cloud is checked index-exactly against the oracle."""
+    B = 4 here; one cloud is checked index-exactly against the oracle.  Also closes the
+    chain for the 19384-point golden: oracle(libm, bs=1) == reference kernel<1> there."""
     rng = np.random.default_rng(1234)
     x = rng.random((4, 19384, 3), dtype=np.float32)
     mm = np.full(4, 0.0085, np.float32)
@@ -185,3 +171,6 @@ def test_hip_full_size_sparenet_shape(dev):
         assert len(set(got[b])) == 16384 and got[b, 0] == 0
     ref = oracle.mds(x[:1], 16384, mm[:1], exp_mode=1)
     assert np.array_equal(got[:1], ref)
+    z = np.load(os.path.join(golden_dir, "mds_1x19384_m1024.npz"))
+    idx = oracle.mds(z["xyz"], int(z["npoint"]), z["mean_mst_length"], exp_mode=0, bs_override=1)
+    assert np.array_equal(idx, z["idx_bs1"])
