@@ -1,0 +1,321 @@
+#!/usr/bin/env python3
+"""bench.py -- SpareNet loss/render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one synthetic batch PER RANK (weak scaling,
+B=32 clouds of N=16384 points each rank -- BASELINE.json configs[1] + configs[2]):
+    Chamfer distance            fwd + bwd   [32,16384,3] <-> [32,16384,3]
+    EMD (auction)               fwd + bwd   eps 0.005, 50 iterations
+    expansion penalty           fwd + bwd   primitive_size 512, alpha 1.5
+    ComputeDepthMaps render     fwd + bwd   8 views x radius_list, 256 x 256
+    scalar losses               all-reduce (RCCL) when N > 1
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
+  value             point pairs per second, whole job (CD pairs 2*B*N*M + EMD effective pairs
+                    sum_it sum_b unassigned*n, counted on the device) / wall time of the steps
+  depthmaps_per_sec single-radius 256x256 maps per second over the same wall time
+  roofline          the dominant kernel (emd_bid): algorithmic flops / its measured launch time
+  cpu_baseline      the CPU oracle (port of the reference algorithm) on a bounded sample
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+B, N = 32, 16384
+EMD_EPS, EMD_ITERS = 0.005, 50
+PRIM, ALPHA = 512, 1.5
+IMG = 256
+N_VIEWS = 8
+FLOP_PER_PAIR = {"chamfer_fwd": 9.0, "emd_bid": 14.0}
+PEAK_F32_TFLOPS = 157.3                                   # MI355X_MICROARCH.md (vector == f32 MFMA peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--radius-list", type=str, default="5,7,10",
+                    help="p2i radii in pixels (reference default, configs/base_config.py:56-60); "
+                         "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def make_inputs(dev, rank):
+    g = torch.Generator().manual_seed(1234 + rank)
+    pred = torch.rand(B, N, 3, generator=g)
+    gt = torch.rand(B, N, 3, generator=g)
+    return pred.to(dev), gt.to(dev)
+
+
+class HotPath:
+    """One training-step worth of loss/render ops, composed like the reference runners
+    (runners/sparenet_runner.py:83-108, runners/sparenet_gan_runner.py:212-225)."""
+
+    def __init__(self, dev, radius_list):
+        from sparenet_amd.cuda.chamfer_distance import ChamferDistance
+        from sparenet_amd.cuda.emd.emd_module import emd_forward_raw, emdFunction
+        from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
+        from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
+        from sparenet_amd import _lib
+
+        self.lib = _lib
+        self.dev = dev
+        self.cd = ChamferDistance()
+        self.emd_raw = emd_forward_raw
+        self.emd_fn = emdFunction
+        self.expansion = expansionPenaltyModule()
+        self.render = ComputeDepthMaps("orthorgonal", 1.0, IMG).to(dev)
+        self.radius_list = radius_list
+        self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.ev = {}
+
+    def _emd(self, pred, gt):
+        """emdFunction with the effective-pair counter attached."""
+        fn = self.emd_fn
+        raw = self.emd_raw
+        stats = self.stats
+
+        class _Counted(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, a, b):
+                d, asg = raw(a.contiguous(), b.contiguous(), EMD_EPS, EMD_ITERS, stats)
+                ctx.save_for_backward(a, b, asg)
+                ctx.mark_non_differentiable(asg)
+                return d, asg
+
+            @staticmethod
+            def backward(ctx, gd, _):
+                return fn.backward(ctx, gd, None)[:2]
+
+        return _Counted.apply(pred, gt)
+
+    def step(self, pred, gt, timers=None):
+        def mark(name):
+            if timers is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                timers.append((name, e))
+
+        mark("start")
+        p = pred.detach().requires_grad_(True)
+        g = gt.detach().requires_grad_(True)
+        d1, d2 = self.cd(p, g)
+        loss_cd = d1.mean() + d2.mean()
+        loss_cd.backward()
+        mark("cd")
+        p2 = pred.detach().requires_grad_(True)
+        dist, _ = self._emd(p2, gt)
+        loss_emd = torch.sqrt(dist).mean(1).mean()
+        loss_emd.backward()
+        mark("emd")
+        p3 = pred.detach().requires_grad_(True)
+        pen, _, mml = self.expansion(p3, PRIM, ALPHA)
+        loss_exp = pen.mean()
+        loss_exp.backward()
+        mark("expansion")
+        p4 = (pred.detach() - 0.5).requires_grad_(True)
+        acc = None
+        for v in range(N_VIEWS):
+            maps = self.render(p4, view_id=v, radius_list=self.radius_list)
+            s = maps.mean()
+            acc = s if acc is None else acc + s
+        acc.backward()
+        mark("render")
+        losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
+        if dist_ready():
+            dist.all_reduce(losses, op=dist.ReduceOp.SUM)
+            losses = losses / dist.get_world_size()
+        mark("allreduce")
+        return losses
+
+
+def dist_ready():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def cpu_baseline():
+    """Time the CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+
+    cores = os.cpu_count() or 1
+    g = torch.Generator().manual_seed(1234)
+    pred = torch.rand(B, N, 3, generator=g).numpy()
+    gt = torch.rand(B, N, 3, generator=g).numpy()
+    nb_cd, nb_emd = 8, 1
+    t0 = time.perf_counter()
+    oracle.chamfer_forward(pred[:nb_cd], gt[:nb_cd], mt=True)
+    t_cd = time.perf_counter() - t0
+    pairs_cd = 2.0 * nb_cd * N * N
+    t0 = time.perf_counter()
+    _, _, aux = oracle.emd_forward(pred[:nb_emd], gt[:nb_emd], EMD_EPS, EMD_ITERS, mt=True,
+                                   return_aux=True)
+    t_emd = time.perf_counter() - t0
+    pairs_emd = float(aux["pairs_eff"])
+    # render sample: one view, one radius, 4 clouds, through the oracle p2i (single thread)
+    from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
+    cdm = ComputeDepthMaps("orthorgonal", 1.0, IMG)
+    data = torch.from_numpy(pred[:4]) - 0.5
+    ij, feat = cdm.project(data, 0)
+    px = ((ij + 1) / 2 * (IMG - 1)).numpy()
+    bi = np.repeat(np.arange(4, dtype=np.int32), N)
+    t0 = time.perf_counter()
+    oracle.p2i_max_forward(px, feat.numpy(), bi, np.zeros((4, 1, IMG, IMG), np.float32), 5.0)
+    t_p2i = time.perf_counter() - t0
+    return {
+        "value": (pairs_cd + pairs_emd) / (t_cd + t_emd),
+        "unit": "point-pairs/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle (C, OpenMP x{cores} threads): Chamfer fwd on {nb_cd} of 32 clouds "
+                   f"({pairs_cd:.3g} pairs, {t_cd:.2f} s) + EMD fwd eps {EMD_EPS} iters {EMD_ITERS} on "
+                   f"{nb_emd} cloud ({pairs_emd:.3g} effective pairs, {t_emd:.2f} s); "
+                   f"p2i max fwd R=5 on 4 clouds x 1 view, 1 thread: {t_p2i:.2f} s"),
+        "depthmaps_per_sec_1thread": 4.0 / t_p2i,
+        "chamfer_pairs_per_sec": pairs_cd / t_cd,
+        "emd_pairs_per_sec": pairs_emd / t_emd,
+    }
+
+
+def main():
+    args = parse()
+    radius_list = [float(r) for r in args.radius_list.split(",")]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    n_gpus = world
+
+    pred, gt = make_inputs(dev, rank)
+    hp = HotPath(dev, radius_list)
+    lib = hp.lib.lib()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        hp.step(pred, gt)
+    barrier()
+    hp.stats.zero_()
+    timers = []
+    if not args.no_roofline:
+        lib.sn_prof_reset()
+        lib.sn_prof_enable(1)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = hp.step(pred, gt, timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.sn_prof_enable(0)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    pairs_emd = hp.stats[0:1].to(torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pairs_emd, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    pairs_cd = 2.0 * B * N * N * args.steps * world
+    pairs_total = pairs_cd + float(pairs_emd.item())
+    maps_total = B * N_VIEWS * len(radius_list) * args.steps * world
+
+    # per-segment times on rank 0 (torch events on the current stream)
+    seg = {}
+    for i in range(1, len(timers)):
+        name, ev = timers[i]
+        if name == "start":
+            continue
+        seg[name] = seg.get(name, 0.0) + timers[i - 1][1].elapsed_time(ev)
+    seg = {k: v / args.steps for k, v in seg.items()}
+
+    roofline = None
+    kernels = {}
+    if not args.no_roofline:
+        for kname in ("chamfer_fwd", "emd_bid", "expansion_fwd", "p2i_max_splat"):
+            ms = ctypes.c_double(0.0)
+            cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
+            kernels[kname] = {"launches": int(cnt), "total_ms": ms.value,
+                              "avg_us": (ms.value / cnt * 1e3) if cnt else None}
+        bid = kernels["emd_bid"]
+        if bid["launches"]:
+            flops = FLOP_PER_PAIR["emd_bid"] * float(hp.stats[0].item())     # this rank
+            achieved = flops / (bid["total_ms"] * 1e-3) / 1e12
+            roofline = {
+                "kernel": "emd_bid_kernel", "bound": "mfma", "achieved": achieved,
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
+                "traffic": None,
+                "note": ("fp32 VALU-bound pairwise search (14 flop/pair, SURVEY 8d); peak = f32 "
+                         "vector = f32 MFMA dense peak 157.3 TFLOP/s; bit-parity forbids FMA "
+                         "contraction, so the non-FMA ceiling is half of it"),
+                "launches": bid["launches"], "avg_launch_us": bid["avg_us"],
+                "pairs_per_launch_avg": float(hp.stats[0].item()) / bid["launches"],
+            }
+            cf = kernels["chamfer_fwd"]
+            if cf["launches"]:
+                roofline["chamfer_fwd"] = {
+                    "achieved": FLOP_PER_PAIR["chamfer_fwd"] * 2.0 * B * N * N * cf["launches"]
+                    / (cf["total_ms"] * 1e-3) / 1e12,
+                    "avg_launch_us": cf["avg_us"]}
+                roofline["chamfer_fwd"]["frac"] = roofline["chamfer_fwd"]["achieved"] / PEAK_F32_TFLOPS
+
+    if rank == 0:
+        out = {
+            "metric": "point-pairs/sec (CD+EMD) + depthmaps/sec, B=32 N=16384",
+            "value": pairs_total / elapsed,
+            "unit": "point-pairs/s",
+            "n_gpus": n_gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "depthmaps_per_sec": maps_total / elapsed,
+            "config": {
+                "workload": ("per rank: CD fwd+bwd + EMD(eps 0.005, 50 it) fwd+bwd + expansion(P=512, "
+                             "alpha 1.5) fwd+bwd on [32,16384,3]; ComputeDepthMaps 8 views x radii "
+                             f"{radius_list} px -> 256x256 fwd+bwd; scalar-loss all-reduce"),
+                "batch_per_gpu": B, "points": N, "emd_iters": EMD_ITERS, "radius_list": radius_list,
+                "image": IMG, "views": N_VIEWS,
+            },
+            "pairs_per_step": pairs_total / args.steps / world,
+            "maps_per_step": maps_total / args.steps / world,
+            "segments_ms_rank0": seg,
+            "kernels_rank0": kernels,
+            "losses": [float(x) for x in losses.tolist()],
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

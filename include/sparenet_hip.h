@@ -40,6 +40,15 @@ int sn_abi_version(void);
 /* thread-local text of the last failure on the calling thread ("" if none) */
 const char *sn_last_error(void);
 
+/* Optional per-kernel timing, off by default (measurement aid, not part of the
+ * reference interface): when enabled the heavy kernels ("chamfer_fwd", "emd_bid",
+ * "expansion_fwd", "mds", "p2i_max_splat") are bracketed by hipEventRecord on the
+ * stream they are launched on.  sn_prof_read waits for the recorded events and returns
+ * the number of launches of `name` since the last reset and their summed duration. */
+void sn_prof_enable(int on);
+long long sn_prof_read(const char *name, double *total_ms);
+void sn_prof_reset(void);
+
 /* ------------------------------------------------------------------ Chamfer
  * replaces cd.forward_cuda  = chamfer_distance_forward_cuda
  *          (cuda/chamfer_distance/chamfer_distance.cpp:26-38,186;

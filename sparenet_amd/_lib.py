@@ -30,6 +30,9 @@ def lib():
                 "g.build()'` or `make -C sparenet_amd/csrc`. sparenet_amd has no CPU fallback.")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sn_last_error.restype = ctypes.c_char_p
+        _lib.sn_prof_read.restype = ctypes.c_longlong
+        _lib.sn_prof_enable.restype = None
+        _lib.sn_prof_reset.restype = None
         for name in ("sn_emd_workspace_bytes", "sn_p2i_max_workspace_bytes",
                      "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes", "sn_mds_workspace_bytes"):
             if hasattr(_lib, name):

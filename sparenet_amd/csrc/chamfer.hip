@@ -259,8 +259,9 @@ extern "C" int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, i
   const int nb_max = nb1 > nb2 ? nb1 : nb2;
   const int clouds_per_xcd = sn::ceil_div(2 * b, 8);
   const int grid = 8 * clouds_per_xcd * nb_max;
-  chamfer_fwd_kernel<<<grid, kThreads, 0, sn::as_stream(stream)>>>(
-      xyz1, xyz2, b, n, m, dist1, idx1, dist2, idx2, nb1, nb2, nb_max);
+  hipStream_t s = sn::as_stream(stream);
+  SN_TIMED("chamfer_fwd", s, (chamfer_fwd_kernel<<<grid, kThreads, 0, s>>>(
+      xyz1, xyz2, b, n, m, dist1, idx1, dist2, idx2, nb1, nb2, nb_max)));
   return sn::launch_status("sn_chamfer_forward");
 }
 

@@ -1,6 +1,12 @@
 // common.hip -- error plumbing and ABI version of libsparenet_hip.so.
 #include "common.hpp"
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace sn {
 
 char *last_error_buf() {
@@ -16,7 +22,74 @@ int fail(int code, const char *fmt, ...) {
   return code;
 }
 
+namespace {
+struct Span {
+  hipEvent_t a, b;
+};
+std::atomic<bool> g_prof{false};
+std::mutex g_mu;
+std::map<std::string, std::vector<Span>> g_spans;
+std::map<std::string, hipEvent_t> g_open;
+}  // namespace
+
+bool prof_enabled() { return g_prof.load(std::memory_order_relaxed); }
+
+void prof_begin(const char *name, hipStream_t s) {
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_open[name] = e;
+}
+
+void prof_end(const char *name, hipStream_t s) {
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  std::lock_guard<std::mutex> lk(g_mu);
+  auto it = g_open.find(name);
+  if (it == g_open.end()) {
+    (void)hipEventDestroy(e);
+    return;
+  }
+  g_spans[name].push_back({it->second, e});
+  g_open.erase(it);
+}
+
 }  // namespace sn
+
+extern "C" void sn_prof_enable(int on) { sn::g_prof.store(on != 0); }
+
+// Sum of the recorded launch durations of `name` since the last reset; waits for the
+// recorded events.  Returns the number of launches (0 if none), total_ms may be NULL.
+extern "C" long long sn_prof_read(const char *name, double *total_ms) {
+  std::lock_guard<std::mutex> lk(sn::g_mu);
+  auto it = sn::g_spans.find(name ? name : "");
+  if (it == sn::g_spans.end()) {
+    if (total_ms) *total_ms = 0.0;
+    return 0;
+  }
+  double tot = 0.0;
+  for (auto &sp : it->second) {
+    (void)hipEventSynchronize(sp.b);
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  return (long long)it->second.size();
+}
+
+extern "C" void sn_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(sn::g_mu);
+  for (auto &kv : sn::g_spans)
+    for (auto &sp : kv.second) {
+      (void)hipEventDestroy(sp.a);
+      (void)hipEventDestroy(sp.b);
+    }
+  sn::g_spans.clear();
+  for (auto &kv : sn::g_open) (void)hipEventDestroy(kv.second);
+  sn::g_open.clear();
+}
 
 extern "C" int sn_abi_version(void) { return SN_ABI_VERSION; }
 extern "C" const char *sn_last_error(void) { return sn::last_error_buf(); }

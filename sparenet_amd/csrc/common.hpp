@@ -36,6 +36,19 @@ inline int launch_status(const char *what) {
       return sn::fail((int)e__, "%s: %s", #call, hipGetErrorString(e__));  \
   } while (0)
 
+// ---- optional per-kernel timing (off by default; used by bench.py's roofline leg).
+// When enabled, the heavy kernels are bracketed by hipEventRecord on their own stream.
+bool prof_enabled();
+void prof_begin(const char *name, hipStream_t s);
+void prof_end(const char *name, hipStream_t s);
+
+#define SN_TIMED(name, stream, launch_expr)                \
+  do {                                                     \
+    if (sn::prof_enabled()) sn::prof_begin(name, stream);  \
+    launch_expr;                                           \
+    if (sn::prof_enabled()) sn::prof_end(name, stream);    \
+  } while (0)
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

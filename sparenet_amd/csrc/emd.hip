@@ -334,9 +334,9 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
   for (int it = 0; it < iters; ++it) {
     const int c = it & 1;
-    emd_bid_kernel<<<bid_grid, kThreads, 0, s>>>(n, xyz1, xyz2, eps, ws.price, ws.bid, ws.bid_inc,
-                                                 ws.max_inc, ws.max_idx, ws.list[c], ws.cnt[c],
-                                                 stats);
+    SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kThreads, 0, s>>>(
+        n, xyz1, xyz2, eps, ws.price, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx, ws.list[c],
+        ws.cnt[c], stats)));
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.cnt[c ^ 1]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,

@@ -246,12 +246,14 @@ extern "C" int sn_expansion_forward(const float *xyz, int b, int n, int primitiv
   hipStream_t s = sn::as_stream(stream);
   float *patch_mean = static_cast<float *>(workspace);
   const dim3 grid(n / P, b);
+  if (sn::prof_enabled()) sn::prof_begin("expansion_fwd", s);
   switch (P <= 64 ? 1 : P / 64) {
     case 1: expansion_fwd_kernel<1><<<grid, 64, 0, s>>>(n, P, xyz, alpha, dist, assignment, patch_mean); break;
     case 2: expansion_fwd_kernel<2><<<grid, 64, 0, s>>>(n, P, xyz, alpha, dist, assignment, patch_mean); break;
     case 4: expansion_fwd_kernel<4><<<grid, 64, 0, s>>>(n, P, xyz, alpha, dist, assignment, patch_mean); break;
     default: expansion_fwd_kernel<8><<<grid, 64, 0, s>>>(n, P, xyz, alpha, dist, assignment, patch_mean); break;
   }
+  if (sn::prof_enabled()) sn::prof_end("expansion_fwd", s);
   expansion_mean_kernel<<<sn::ceil_div(b, 64), 64, 0, s>>>(b, n / P, patch_mean, mean_mst_length);
   return sn::launch_status("sn_expansion_forward");
 }

@@ -250,6 +250,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
   }
   const int ppt = (n + bs - 1) / bs;
   hipStream_t s = sn::as_stream(stream);
+  if (sn::prof_enabled()) sn::prof_begin("mds", s);
 #define SN_MDS(P) mds_kernel<P, 0, 1024><<<b, 1024, 0, s>>>(n, m, xyz, mean_mst_length, idx, lg)
 #define SN_MDS_Z(P, C) \
   mds_kernel<P, C, 1024><<<b, 1024, (size_t)n * 4 * C, s>>>(n, m, xyz, mean_mst_length, idx, lg)
@@ -285,6 +286,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
   }
 #undef SN_MDS
 #undef SN_MDS_Z
+  if (sn::prof_enabled()) sn::prof_end("mds", s);
   return sn::launch_status("sn_mds");
 }
 

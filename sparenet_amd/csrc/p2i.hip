@@ -261,6 +261,7 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
 #define SN_SPLAT(L)                                                                          \
   p2i_max_splat_kernel<L><<<(int)blocks, 256, 0, s>>>(points, feat, batch_inds, img, npoints, \
                                                       channels, batch, h, w, radius)
+    if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
     switch (lpp) {
       case 4: SN_SPLAT(4); break;
       case 8: SN_SPLAT(8); break;
@@ -268,6 +269,7 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
       case 32: SN_SPLAT(32); break;
       default: SN_SPLAT(64); break;
     }
+    if (sn::prof_enabled()) sn::prof_end("p2i_max_splat", s);
 #undef SN_SPLAT
   }
   p2i_max_finalize_kernel<<<lin_blocks(px), 256, 0, s>>>(img, out, out_ids, px);
