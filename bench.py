@@ -32,6 +32,8 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+from sparenet_amd.dist_utils import reduce_mean_of_means  # noqa: E402
+
 B, N = 32, 16384
 EMD_EPS, EMD_ITERS = 0.005, 50
 PRIM, ALPHA = 512, 1.5
@@ -136,15 +138,9 @@ class HotPath:
         acc.backward()
         mark("render")
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
-        if dist_ready():
-            dist.all_reduce(losses, op=dist.ReduceOp.SUM)
-            losses = losses / dist.get_world_size()
+        losses = reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
         mark("allreduce")
         return losses
-
-
-def dist_ready():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def cpu_baseline():

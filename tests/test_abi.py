@@ -1,0 +1,87 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol that
+include/sparenet_hip.h declares (no compute calls here), argument validation returns
+SN_EINVAL with a message, and the product path refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "sparenet_hip.h")).read()
+    return sorted(set(re.findall(
+        r"^(?:int|size_t|void|long long|const char \*)\s*(sn_[a-z0-9_]+)\s*\(", hdr, re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    import sparenet_amd
+
+    lib = sparenet_amd.lib()
+    names = _declared()
+    assert len(names) >= 28
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/sparenet_hip.h but not exported"
+    assert lib.sn_abi_version() == 1
+
+
+def test_argument_validation_without_gpu():
+    import sparenet_amd
+
+    lib = sparenet_amd.lib()
+    null = ctypes.c_void_p(0)
+    assert lib.sn_chamfer_forward(null, null, 1, 1, 1, null, null, null, null, null) == -22
+    assert b"null pointer" in lib.sn_last_error()
+    one = ctypes.c_void_p(8)  # never dereferenced: validation fails first
+    assert lib.sn_emd_forward(one, one, 1, 1000, ctypes.c_float(0.005), 5, one, one, one,
+                              ctypes.c_size_t(1 << 30), null, null) == -22
+    assert b"multiple of 1024" in lib.sn_last_error()
+    assert lib.sn_expansion_forward(one, 1, 768, 384, ctypes.c_float(1.5), one, one, one, one,
+                                    ctypes.c_size_t(1 << 20), null) == -22
+    assert b"power of two" in lib.sn_last_error()
+    assert lib.sn_mds(one, 1, 10, 20, one, one, null, ctypes.c_size_t(0), null) == -22
+    lib.sn_emd_workspace_bytes.restype = ctypes.c_size_t
+    assert lib.sn_emd_workspace_bytes(32, 16384) == 8 * 32 * 16384 * 4 + 2 * 256
+
+
+def test_no_cpu_fallback_anywhere():
+    from sparenet_amd import SparenetHipError
+    from sparenet_amd.cuda.emd.emd_module import emdModule
+    from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
+    from sparenet_amd.cuda.MDS.MDS_module import gather_operation, minimum_density_sample
+    from sparenet_amd.cuda.p2i_op import p2i
+    from sparenet_amd.cuda.gridding import Gridding, GriddingReverse
+    from sparenet_amd.cuda.cubic_feature_sampling import CubicFeatureSampling
+
+    x = torch.rand(1, 1024, 3)
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        emdModule()(x, x, 0.005, 2)
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        expansionPenaltyModule()(x, 512, 1.5)
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        minimum_density_sample(x, 16, torch.ones(1))
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        gather_operation(torch.rand(1, 3, 8), torch.zeros(1, 4, dtype=torch.int32))
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        p2i(torch.rand(4, 2), torch.rand(4, 1), torch.zeros(4, dtype=torch.int32),
+            torch.zeros(1, 1, 8, 8), 2.0, "cos", "max")
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        Gridding(8)(torch.rand(1, 16, 3) * 0.5)
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        GriddingReverse(4)(torch.rand(1, 4, 4, 4))
+    with pytest.raises((SparenetHipError, RuntimeError)):
+        CubicFeatureSampling()(torch.rand(1, 8, 3), torch.rand(1, 2, 4, 4, 4))
+
+
+def test_product_package_never_imports_the_oracle():
+    bad = []
+    for dp, _, files in os.walk(os.path.join(ROOT, "sparenet_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                txt = open(os.path.join(dp, f)).read()
+                if re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M) or "liboracle" in txt:
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
