@@ -29,15 +29,16 @@
 //   * GetMax: deterministic atomicMax of the bidder index inside the window.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
-constexpr int kThreads = 256;
-constexpr int kTile = 1024;      // targets per LDS tile (SoA x,y,z,price = 16 KB)
-constexpr int kBlocksPerCloud = 64;
+constexpr int kThreads = 256;     // element-wise kernels
+constexpr int kBlocksPerCloud = 16;  // bid kernel: 16 workgroups x 16 waves = 256 waves per cloud
 
 struct Top2 {
   float best, better;
-  int best_i;
+  int best_i, better_i;  // best_i: canonical among exact ties (see tie_key); better_i: a hint
 };
 
 __device__ __forceinline__ float bid_value(float tx, float ty, float tz, float p, float x1,
@@ -49,20 +50,99 @@ __device__ __forceinline__ float bid_value(float tx, float ty, float tz, float p
   return (float)((3.0 - (double)__builtin_sqrtf(s)) - (double)p);
 }
 
-__device__ __forceinline__ void top2_push(Top2 &t, float d, int k) {
-  // if (d > best) {better = best; best = d; best_i = k} else if (d > better) better = d
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// two targets at once; identical rounding to sq_dist, component-wise
+__device__ __forceinline__ f2 sq_dist2(f2 tx, f2 ty, f2 tz, float x1, float y1, float z1) {
+#pragma clang fp contract(off)
+  const f2 dx = tx - x1, dy = ty - y1, dz = tz - z1;
+  const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
+}
+
+__device__ __forceinline__ float sq_dist(float tx, float ty, float tz, float x1, float y1,
+                                         float z1) {
+#pragma clang fp contract(off)
+  const float dx = tx - x1, dy = ty - y1, dz = tz - z1;
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
+}
+
+// Exact ties at the top.  The reference's Bid resolves d_k == best to
+// argmin (thread(k), k): thread(k) = ((k mod 2048) / delta), delta = ceil(end_k / tpu)
+// (emd_cuda.cu:136-139, :166-173).  key(k) = thread(k) * 2^20 + k orders those candidates.
+struct TieGeom {
+  int n, tpu;
+};
+__device__ __forceinline__ int tie_key(const TieGeom &g, int k) {
+  const int k2 = (k / 2048) * 2048;
+  const int end_k = (g.n < k2 + 2048 ? g.n : k2 + 2048) - k2;
+  const int delta = (end_k + g.tpu - 1) / g.tpu;
+  return ((k - k2) / delta) * (1 << 20) + k;  // n <= 2^20 (host check)
+}
+
+// if (d > best) {better = best; best = d; best_i = k} else if (d > better) better = d,
+// plus: on d == best the candidate with the smaller tie key becomes best_i (values unchanged:
+// better becomes best through the "else if").  Runs only on the exact path.
+__device__ __forceinline__ void top2_push(Top2 &t, float d, int k, const TieGeom &g) {
+  if (__any(d == t.best && t.best_i >= 0)) {  // rare: an exact tie with the running best
+    if (d == t.best && t.best_i >= 0 && tie_key(g, k) < tie_key(g, t.best_i)) {
+      const int o = t.best_i;
+      t.best_i = k;
+      k = o;  // the displaced index is an equally valid witness for `better`
+    }
+  }
   const bool gt = d > t.best;
-  t.better = __builtin_fmaxf(t.better, __builtin_fminf(d, t.best));
+  const bool mid = !gt && d > t.better;
+  t.better_i = gt ? t.best_i : (mid ? k : t.better_i);
+  t.better = gt ? t.best : (mid ? d : t.better);
   t.best_i = gt ? k : t.best_i;
   t.best = gt ? d : t.best;
 }
 
-__device__ __forceinline__ void top2_merge(Top2 &a, float b_best, float b_better, int b_i) {
-  const bool gt = b_best > a.best;
-  const float lo = gt ? a.best : b_best;
-  a.better = __builtin_fmaxf(__builtin_fmaxf(a.better, b_better), lo);
-  a.best_i = gt ? b_i : a.best_i;
-  a.best = gt ? b_best : a.best;
+// top-2 of the union of two partial results; equal best values keep the smaller tie key
+__device__ __forceinline__ void top2_merge(Top2 &a, float b_best, float b_better, int b_i,
+                                           int b_i2, const TieGeom &g) {
+  if (b_best > a.best) {
+    const bool keep_a = a.best >= b_better;
+    a.better = keep_a ? a.best : b_better;
+    a.better_i = keep_a ? a.best_i : b_i2;
+    a.best = b_best;
+    a.best_i = b_i;
+  } else {
+    if (b_best == a.best && b_i >= 0 && a.best_i >= 0 && tie_key(g, b_i) < tie_key(g, a.best_i)) {
+      const int o = a.best_i;
+      a.best_i = b_i;
+      b_i = o;
+    }
+    const bool take_b = b_best > a.better;
+    a.better = take_b ? b_best : a.better;
+    a.better_i = take_b ? b_i : a.better_i;
+  }
+}
+
+// ---- conservative fp32 filter --------------------------------------------------------
+// A target k can change a lane's top-2 only if d_k > c, c = the lane's running `better`
+// (or any proven lower bound of the bidder's final `better`).  With q = sqrtf(s):
+//   d_k > c  =>  3 - q - p_k > c - 1e-15  =>  q < (3 - p_k - c) + 1e-15  =: R
+//   =>  s < R^2 (1 + 2^-22).
+// The filter evaluates R' = A'_k - c' in fp32 with A'_k = fl(3 - p_k) + eps (3 + |p_k|) and
+// c' = c - eps (3 + |c|), eps = 2^-20: the two margins exceed every rounding error of the
+// filter itself (<= 2^-22 (6 + |p| + |c|)) and the relative slack needed on R, so
+// "s <= R' |R'|" is implied by d_k >= c.  Only targets that pass go through the exact
+// path (correctly rounded sqrt, fp64 detour, top-2 update); everything else costs
+// 8 (distance) + 3 (filter) VALU ops instead of ~45.
+constexpr float kFilterEps = 9.5367431640625e-07f;  // 2^-20
+
+__device__ __forceinline__ float filter_target(float p) {
+  return (3.0f - p) + (3.0f + __builtin_fabsf(p)) * kFilterEps;
+}
+__device__ __forceinline__ float filter_thr(float c) {
+  return c - (3.0f + __builtin_fabsf(c)) * kFilterEps;
+}
+__device__ __forceinline__ bool filter_pass(float s, float a_k, float cthr) {
+  const float r = a_k - cthr;
+  return s <= r * __builtin_fabsf(r);
 }
 
 // order-preserving float max through integer atomics
@@ -73,18 +153,29 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
     atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
 }
 
+// Prepared target stream: one 32-byte record per PAIR of targets,
+//   [x0 x1 | y0 y1 | z0 z1 | A'0 A'1],  A'_k = filter_target(price_k),
+// so that a wave-uniform s_load_dwordx16 delivers 4 targets straight into SGPR pairs that
+// the packed fp32 ops consume as operands.  Written by emd_init_kernel, A' refreshed by
+// emd_assign_kernel for the targets whose price changed.
+__device__ __forceinline__ size_t tgt_slot(int k, int field) {
+  return (size_t)(k >> 1) * 8 + field * 2 + (k & 1);
+}
+
 struct EmdWs {
   int *assignment_inv;
   float *price;
-  int *bid;
+  int *bid, *bid2;
   float *bid_inc;
   float *max_inc;
   int *max_idx;
   int *list[2];
   int *cnt[2];
+  float *tgt;  // [B, n/2, 8] prepared target stream (see tgt_slot)
 };
 
-__global__ void emd_init_kernel(int B, int n, int *__restrict__ assignment, EmdWs ws) {
+__global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
+                                int *__restrict__ assignment, EmdWs ws) {
   const long total = (long)B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
@@ -93,7 +184,18 @@ __global__ void emd_init_kernel(int B, int n, int *__restrict__ assignment, EmdW
     ws.price[e] = 0.f;
     ws.max_inc[e] = 0.f;  // emd_module.py:49 (zeros, not -1e9)
     ws.max_idx[e] = 0;
+    ws.bid[e] = -1;   // no previous favourites yet (filter seeding)
+    ws.bid2[e] = -1;
     ws.list[0][e] = (int)(e % n);
+    {
+      const long bb = e / n;
+      const int k = (int)(e - bb * n);
+      float *t = ws.tgt + bb * n * 4;
+      t[tgt_slot(k, 0)] = xyz2[e * 3 + 0];
+      t[tgt_slot(k, 1)] = xyz2[e * 3 + 1];
+      t[tgt_slot(k, 2)] = xyz2[e * 3 + 2];
+      t[tgt_slot(k, 3)] = filter_target(0.f);
+    }
     if (e < B) {
       ws.cnt[0][e] = n;
       ws.cnt[1][e] = 0;
@@ -101,111 +203,169 @@ __global__ void emd_init_kernel(int B, int n, int *__restrict__ assignment, EmdW
   }
 }
 
-// lanes per bidder for a cloud with U bidders: largest 2^k <= lanes/U, in [1,64]
-__device__ __forceinline__ int lanes_per_bidder(int U) {
-  const int lanes = kBlocksPerCloud * kThreads;
-  int T = 1;
-  while (T < 64 && T * 2 * U <= lanes) T *= 2;
-  return T;
+struct BidOut {
+  int *bid, *bid2;
+  float *bid_inc, *max_inc;
+  int *max_idx;
+};
+
+// ---------------------------------------------------------------------------------------
+// Bid kernel.  Every lane of a wave is a DIFFERENT bidder and the whole wave walks the SAME
+// targets, so targets are wave-uniform and travel through the scalar cache into SGPRs
+// (measured: feeding them through LDS as broadcast ds_read_b128 is LDS-issue bound at
+// ~45 cycles per target step; the packed-math filter itself needs ~26).
+// A workgroup has 16 waves.  S = 2^k <= 16 waves share one group of 64 bidders, wave s
+// scanning targets [s n/S, (s+1) n/S); the S partial top-2's meet in LDS.  S is chosen on
+// the device from the unassigned count so that the fixed grid stays busy when few bidders
+// are left (tail iterations), and is 1 while there are >= 64 * waves bidders.
+// ---------------------------------------------------------------------------------------
+constexpr int kBidWaves = 16;
+constexpr int kBidThreads = kBidWaves * 64;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const float cfloat;
+typedef __attribute__((address_space(4))) const f4 cf4;
+
+// constant address space (4): nothing in the bid kernel writes the target stream or the
+// prices, and a uniform load from AS4 is always selected as a scalar (SMEM) load; the 64-bit
+// base goes through readfirstlane so that it provably lives in SGPRs.
+__device__ __forceinline__ const cfloat *uniform_ptr(const float *q) {
+  const unsigned long long a = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (const cfloat *)(((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(kThreads) void emd_bid_kernel(
-    int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2, float eps,
-    const float *__restrict__ price, int *__restrict__ bid, float *__restrict__ bid_inc,
-    float *__restrict__ max_inc, int *__restrict__ max_idx, const int *__restrict__ list,
-    const int *__restrict__ cnt, long long *__restrict__ stats) {
-  __shared__ float sx[kTile], sy[kTile], sz[kTile], sp[kTile];
-  const int b = blockIdx.y;
+// 8 waves/SIMD (<= 64 VGPRs): every wave has at most two scalar loads in flight, so the
+// scalar-cache latency is hidden by wave-level parallelism
+__global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
+    int B, int G, int n, float eps, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
+    const float *__restrict__ price, const float *__restrict__ tgt,
+    const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
+    long long *__restrict__ stats) {
+  __shared__ float m_best[kBidWaves][64], m_better[kBidWaves][64];
+  __shared__ int m_bi[kBidWaves][64], m_bi2[kBidWaves][64];
+  // XCD-aware decode of the 1-D grid: workgroup `lin` runs on XCD lin % 8 and every cloud's
+  // workgroups share that residue, so a cloud's 256 KB target stream + prices stay in ONE
+  // 4 MB L2 (4 clouds per XCD at B = 32) instead of all 8 MB cycling through every L2.
+  const int lin = blockIdx.x;
+  const int xcd = lin & 7, rr = lin >> 3;
+  const int b = (rr / G) * 8 + xcd;
+  const int bx = rr % G;  // this workgroup's index among its cloud's G workgroups
+  if (b >= B) return;
   const int U = cnt[b];
   if (U == 0) return;
-  if (stats && blockIdx.x == 0 && threadIdx.x == 0) {
+  if (stats && bx == 0 && threadIdx.x == 0) {
     atomicAdd(reinterpret_cast<unsigned long long *>(stats), (unsigned long long)U * n);
     if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1, 1ULL);
   }
-  const int T = lanes_per_bidder(U);
-  const int per_block = kThreads / T;
-  const int tid = threadIdx.x;
-  const int t = tid & (T - 1);
-  const int g = tid / T;
-  const float *__restrict__ p1 = xyz1 + (size_t)b * n * 3;
-  const float *__restrict__ p2 = xyz2 + (size_t)b * n * 3;
-  const float *__restrict__ pr = price + (size_t)b * n;
-  const int *__restrict__ lst = list + (size_t)b * n;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably uniform
+  const int lane = threadIdx.x & 63;
+  const size_t o = (size_t)b * n;
+  const float *__restrict__ p1 = xyz1 + o * 3;
+  const float *__restrict__ p2 = xyz2 + o * 3;
+  const float *__restrict__ pr = price + o;
+  const int *__restrict__ lst = list + o;
+  const cfloat *tg = uniform_ptr(tgt + o * 4);
+  const cfloat *prc = uniform_ptr(price + o);
+
+  const int ngroups = (U + 63) >> 6;
+  int S = 1;
+  while (S < kBidWaves && S * 2 * ngroups <= G * kBidWaves) S *= 2;
+  const int gpb = kBidWaves / S;   // bidder groups per workgroup
+  const int seg = wave & (S - 1);  // this wave's target segment
+  const int gslot = wave / S;
+  const int seg_len = n / S;       // n % 1024 == 0, S <= 16: a multiple of 64
+  const int k_begin = seg * seg_len, k_end = k_begin + seg_len;
 
   // reference partition, only needed to order exact ties (emd_cuda.cu:108-109,136)
   const int block_cnt = n / 1024;
-  const int tpu_ref = 1024 / ((U + block_cnt - 1) / block_cnt);
+  const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
 
-  for (int u0 = blockIdx.x * per_block; u0 < U; u0 += gridDim.x * per_block) {
-    const int u = u0 + g;
-    const bool active = u < U;
-    const int j = active ? lst[u] : 0;
+  for (int g0 = bx * gpb; g0 < ngroups; g0 += G * gpb) {  // uniform per block
+    const int grp = g0 + gslot;
+    const int u = grp * 64 + lane;
+    const bool active = grp < ngroups && u < U;
+    const int j = lst[active ? u : 0];
     const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
-    Top2 top = {-1e9f, -1e9f, -1};
+    Top2 top = {-1e9f, -1e9f, -1, -1};
 
-    for (int k0 = 0; k0 < n; k0 += kTile) {
-      __syncthreads();
-      for (int k = tid; k < kTile; k += kThreads) {  // n % 1024 == 0: tiles are full
-        sx[k] = p2[(k0 + k) * 3 + 0];
-        sy[k] = p2[(k0 + k) * 3 + 1];
-        sz[k] = p2[(k0 + k) * 3 + 2];
-        sp[k] = pr[k0 + k];
-      }
-      __syncthreads();
-#pragma unroll 4
-      for (int k = t; k < kTile; k += T) {
-        const float d = bid_value(sx[k], sy[k], sz[k], sp[k], x1, y1, z1);
-        top2_push(top, d, k0 + k);
+    // seed the filter with the bidder's previous two favourites under today's prices:
+    // both are real targets, so the final `better` is at least the smaller of the two.
+    float cm = -1e9f;
+    {
+      const int pa = A.bid[o + j], pb = A.bid2[o + j];
+      if (pa >= 0 && pb >= 0) {
+        const float da = bid_value(p2[pa * 3], p2[pa * 3 + 1], p2[pa * 3 + 2], pr[pa], x1, y1, z1);
+        const float db = bid_value(p2[pb * 3], p2[pb * 3 + 1], p2[pb * 3 + 2], pr[pb], x1, y1, z1);
+        cm = __builtin_fminf(da, db);
       }
     }
-    // merge the T partial results (lanes of a bidder are contiguous, T <= 64)
-    for (int m = 1; m < T; m <<= 1) {
-      const float ob = __shfl_xor(top.best, m);
-      const float os = __shfl_xor(top.better, m);
-      const int oi = __shfl_xor(top.best_i, m);
-      top2_merge(top, ob, os, oi);
-    }
-    // exact tie at the top: canonical best_i = argmin (thread_ref(k), k)
-    const bool tied = active && (top.best == top.better);
-    if (__syncthreads_or(tied)) {
-      int key = 0x7fffffff;
-      for (int k0 = 0; k0 < n; k0 += kTile) {
-        __syncthreads();
-        for (int k = tid; k < kTile; k += kThreads) {
-          sx[k] = p2[(k0 + k) * 3 + 0];
-          sy[k] = p2[(k0 + k) * 3 + 1];
-          sz[k] = p2[(k0 + k) * 3 + 2];
-          sp[k] = pr[k0 + k];
-        }
-        __syncthreads();
-        if (tied) {
-          // 2048-tile geometry of the reference for this k0
-          const int ref_k2 = (k0 / 2048) * 2048;
-          const int end_k = (n < ref_k2 + 2048 ? n : ref_k2 + 2048) - ref_k2;
-          const int delta = (end_k + tpu_ref - 1) / tpu_ref;
-          for (int k = t; k < kTile; k += T) {
-            const float d = bid_value(sx[k], sy[k], sz[k], sp[k], x1, y1, z1);
-            if (d == top.best) {
-              const int kk = k0 + k;
-              const int thr = (kk - ref_k2) / delta;
-              const int cand = thr * (1 << 20) + kk;  // n <= 2^20 checked by the host
-              key = cand < key ? cand : key;
+    float cthr = filter_thr(cm);
+    int n_slow_groups = 0, n_exact = 0;  // wave-uniform diagnostics (stats[2], stats[3])
+
+    if (grp < ngroups) {  // wave-uniform
+      // software pipelined: the next 4 targets' record pair (s_load_dwordx16) is in flight
+      // while the current 4 are evaluated
+      const cf4 *rec = (const cf4 *)(tg + (size_t)(k_begin >> 1) * 8);
+      f4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
+      for (int k = k_begin; k < k_end; k += 4) {
+        const f4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;  // [x0 x1 y0 y1][z0 z1 a0 a1] x 2
+        rec += (k + 4 < k_end) ? 4 : 0;
+        n0 = rec[0];
+        n1 = rec[1];
+        n2 = rec[2];
+        n3 = rec[3];
+        const f2 s01 = sq_dist2(f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, x1, y1, z1);
+        const f2 s23 = sq_dist2(f2{c2.x, c2.y}, f2{c2.z, c2.w}, f2{c3.x, c3.y}, x1, y1, z1);
+        const f2 r01 = f2{c1.z, c1.w} - cthr, r23 = f2{c3.z, c3.w} - cthr;
+        // s <= R |R|: a negative R (target too expensive to matter at any distance) never passes
+        const float t0 = r01.x * __builtin_fabsf(r01.x), t1 = r01.y * __builtin_fabsf(r01.y);
+        const float t2 = r23.x * __builtin_fabsf(r23.x), t3 = r23.y * __builtin_fabsf(r23.y);
+        const float sq[4] = {s01.x, s01.y, s23.x, s23.y};
+        const bool pass[4] = {s01.x <= t0, s01.y <= t1, s23.x <= t2, s23.y <= t3};
+        // one wave-uniform branch per 4 targets; the exact path is out of line.  A filter
+        // evaluated with an older (looser) threshold only passes more, never less.
+        if (__builtin_expect(__any(pass[0] | pass[1] | pass[2] | pass[3]), 0)) {
+          const int ku = __builtin_amdgcn_readfirstlane(k);
+          ++n_slow_groups;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (__any(pass[i])) {
+              ++n_exact;
+              const float d =
+                  (float)((3.0 - (double)__builtin_sqrtf(sq[i])) - (double)prc[ku + i]);
+              if (pass[i]) top2_push(top, d, ku + i, geom);
+              cm = __builtin_fmaxf(cm, top.better);
+              cthr = filter_thr(cm);
             }
           }
         }
       }
-      for (int m = 1; m < T; m <<= 1) {
-        const int ok = __shfl_xor(key, m);
-        key = ok < key ? ok : key;
-      }
-      if (tied) top.best_i = key & ((1 << 20) - 1);
     }
-    if (active && t == 0) {
+    if (stats && lane == 0 && grp < ngroups) {
+      atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 2, (unsigned long long)n_slow_groups);
+      atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 3, (unsigned long long)n_exact);
+    }
+    // merge the S partial results of a bidder group (segment 0's wave collects)
+    if (S > 1) {
+      m_best[wave][lane] = top.best;
+      m_better[wave][lane] = top.better;
+      m_bi[wave][lane] = top.best_i;
+      m_bi2[wave][lane] = top.better_i;
+      __syncthreads();
+      if (seg == 0)
+        for (int w = wave + 1; w < wave + S; ++w)
+          top2_merge(top, m_best[w][lane], m_better[w][lane], m_bi[w][lane], m_bi2[w][lane], geom);
+      __syncthreads();  // LDS merge slots are reused by the next group
+    }
+    if (active && seg == 0) {
       const float inc = (top.best - top.better) + eps;
-      bid[(size_t)b * n + j] = top.best_i;
-      bid_inc[(size_t)b * n + j] = inc;
-      atomic_max_float(&max_inc[(size_t)b * n + top.best_i], inc);
-      max_idx[(size_t)b * n + top.best_i] = -1;  // winner is re-derived by emd_getmax_kernel
+      A.bid[o + j] = top.best_i;
+      A.bid2[o + j] = top.better_i == top.best_i ? -1 : top.better_i;
+      A.bid_inc[o + j] = inc;
+      atomic_max_float(&A.max_inc[o + top.best_i], inc);
+      A.max_idx[o + top.best_i] = -1;  // winner is re-derived by emd_getmax_kernel
     }
   }
 }
@@ -232,7 +392,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
     float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     float *__restrict__ max_inc, const int *__restrict__ max_idx, const int *__restrict__ list,
     const int *__restrict__ cnt, int *__restrict__ list_next, int *__restrict__ cnt_next,
-    int last) {
+    float *__restrict__ tgt_stream, int last) {
   const int b = blockIdx.y;
   const int U = cnt[b];
   const size_t o = (size_t)b * n;
@@ -247,7 +407,9 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       }
       assignment_inv[o + tgt] = j;
       assignment[o + j] = tgt;
-      price[o + tgt] += bid_inc[o + j];
+      const float np = price[o + tgt] + bid_inc[o + j];
+      price[o + tgt] = np;
+      tgt_stream[o * 4 + tgt_slot(tgt, 3)] = filter_target(np);  // keep the bid filter in sync
       max_inc[o + tgt] = -1e9f;
     } else {
       list_next[o + atomicAdd(&cnt_next[b], 1)] = j;
@@ -297,13 +459,15 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.assignment_inv = reinterpret_cast<int *>(p); p += arr;
   ws.price = reinterpret_cast<float *>(p); p += arr;
   ws.bid = reinterpret_cast<int *>(p); p += arr;
+  ws.bid2 = reinterpret_cast<int *>(p); p += arr;
   ws.bid_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_idx = reinterpret_cast<int *>(p); p += arr;
   ws.list[0] = reinterpret_cast<int *>(p); p += arr;
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
   ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
-  ws.cnt[1] = reinterpret_cast<int *>(p);
+  ws.cnt[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
+  ws.tgt = reinterpret_cast<float *>(p);
   return ws;
 }
 
@@ -311,7 +475,8 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 8 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256);
+  return 9 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+         sn::align_up((size_t)b * n * 16, 256);
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
@@ -329,20 +494,21 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
-  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, assignment, ws);
-  const dim3 bid_grid(kBlocksPerCloud, b);
+  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
+  static const int g_env = getenv("SN_EMD_G") ? atoi(getenv("SN_EMD_G")) : kBlocksPerCloud;
+  const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
   for (int it = 0; it < iters; ++it) {
     const int c = it & 1;
-    SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kThreads, 0, s>>>(
-        n, xyz1, xyz2, eps, ws.price, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx, ws.list[c],
-        ws.cnt[c], stats)));
+    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx};
+    SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
+        b, g_env, n, eps, xyz1, xyz2, ws.price, ws.tgt, ws.list[c], ws.cnt[c], bo, stats)));
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.cnt[c ^ 1]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
                                                     ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.list[c ^ 1],
-                                                    ws.cnt[c ^ 1], it == iters - 1);
+                                                    ws.cnt[c ^ 1], ws.tgt, it == iters - 1);
   }
   emd_calcdist_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, assignment, dist);
   return sn::launch_status("sn_emd_forward");
