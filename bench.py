@@ -82,7 +82,7 @@ class HotPath:
         self.expansion = expansionPenaltyModule()
         self.render = ComputeDepthMaps("orthorgonal", 1.0, IMG).to(dev)
         self.radius_list = radius_list
-        self.stats = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ev = {}
 
     def _emd(self, pred, gt):

@@ -73,12 +73,11 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
  *          (cuda/emd/emd_module.py:43-54): they live in `workspace` here.
  * Requirements as the reference: n % 1024 == 0, b <= 512 (emd_module.py:36-39).
  * dist[b,n] fp32, assignment[b,n] int32.
- * stats (optional device pointer, may be NULL): 4 x int64, zeroed by the caller
+ * stats (optional device pointer, may be NULL): 2 x int64, zeroed by the caller
  *   stats[0] += sum over iterations and batch of unassigned_count * n
  *               (effective pair evaluations); stats[1] += iterations that had
- *               at least one bidder; stats[2] += wave-level 4-target groups that
- *               left the fp32 filter path; stats[3] += wave-level exact
- *               (sqrt + fp64) target evaluations. */
+ *               at least one bidder (one atomic per cloud per iteration: per-wave
+ *               counters on one address measurably serialise the bid kernel). */
 size_t sn_emd_workspace_bytes(int b, int n);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,

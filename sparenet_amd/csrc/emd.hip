@@ -8,33 +8,34 @@
 //              s = (dx*dx + dy*dy) + dz*dz, separately rounded, dx = xyz2 - xyz1;
 //   per bidder best = max d, better = second max (duplicates count, init -1e9);
 //   exact ties at the top resolve to argmin (thread(k), k), thread(k) being the
-//   reference's chunk of the 2048-tile (emd_cuda.cu:136-139) -- handled by a rare
-//   re-scan, because the top-2 VALUES are partition independent;
+//   reference's chunk of the 2048-tile (emd_cuda.cu:136-139) -- tracked on the exact
+//   path through a canonical key, because the top-2 VALUES are partition independent;
 //   GetMax window +-1e-6 in double; several bidders inside the window -> highest
 //   bidder index (what a sequential ascending-j run of :188-191 gives; a race on
 //   the reference's GPU); Assign/eviction/price update/last-iteration force
 //   assignment exactly as :196-215.
 //
-// MI355X design
-//   * 3 launches per iteration instead of 7: the unassigned list for the next
-//     iteration is produced by Assign itself (losers and evicted points append
-//     with a wave-aggregated atomic) -- no count / scan / compaction kernels.
-//   * Bid: the unassigned count U_b is only known on the device, so a fixed grid
-//     (G blocks per cloud) adapts: T = lanes per bidder = 2^k <= 64 chosen from
-//     U_b so that all G*256 lanes of a cloud are busy; each lane scans the
-//     targets t, t+T, ... of every LDS tile (SoA x|y|z|price, conflict-free for
-//     any T, pure broadcast for T=1) and the T partial top-2's merge with a
-//     wave64 xor-butterfly (no LDS, no barrier).  Tail iterations with a
-//     handful of bidders therefore still spread over whole waves.
+// MI355X design (measured history in DESIGN.md section 5)
+//   * 4 launches per iteration instead of 7: the unassigned list for the next iteration is
+//     produced by Assign itself (losers and evicted points append with a wave-aggregated
+//     atomic) -- no count / scan / compaction kernels.
+//   * Bid is the hot kernel (fp32 VALU bound).  Every lane of a wave is a different bidder
+//     and the wave walks a wave-UNIFORM target stream that arrives through the scalar cache
+//     in SGPRs (one s_load_dwordx16 = 4 targets) -- no LDS, no barrier in the scan.
+//   * fp32 packed filter + exact path: a target is evaluated exactly (correctly rounded
+//     sqrt, fp64 detour, top-2 update) only if a conservative fp32 test says it could enter
+//     the bidder's top-2; thresholds are seeded from the bidder's previous two favourites.
+//     ~2-4 % of the wave-steps take the exact path; results stay bit-identical.
+//   * the unassigned count is only known on the device, so a fixed XCD-aware grid adapts:
+//     S = 2^k <= 64 waves share one group of 64 bidders, each scanning n/S targets; up to
+//     16 of them merge in LDS, the rest through emd_bid_finish_kernel.
 //   * GetMax: deterministic atomicMax of the bidder index inside the window.
 #include "common.hpp"
-
-#include <cstdlib>
 
 namespace {
 
 constexpr int kThreads = 256;     // element-wise kernels
-constexpr int kBlocksPerCloud = 16;  // bid kernel: 16 workgroups x 16 waves = 256 waves per cloud
+constexpr int kBlocksPerCloud = 32;  // bid kernel: 32 workgroups x 16 waves = 512 waves per cloud (swept 8..64)
 
 struct Top2 {
   float best, better;
@@ -172,6 +173,7 @@ struct EmdWs {
   int *list[2];
   int *cnt[2];
   float *tgt;  // [B, n/2, 8] prepared target stream (see tgt_slot)
+  float *partial;  // [B][16][4][64] float4
 };
 
 __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
@@ -207,7 +209,41 @@ struct BidOut {
   int *bid, *bid2;
   float *bid_inc, *max_inc;
   int *max_idx;
+  float4 *partial;  // [B][kMaxSplitGroups][kMaxSplit][64] cross-workgroup partial top-2's
 };
+
+constexpr int kBidWaves = 16;
+constexpr int kBidThreads = kBidWaves * 64;
+constexpr int kMaxSegments = 64;                          // waves per bidder group, at most
+constexpr int kMaxSplit = kMaxSegments / kBidWaves;       // workgroups per bidder group, at most
+constexpr int kMaxSplitGroups = 16;                       // groups per cloud that may be split
+
+// How a cloud's G*16 waves are spread over its ngroups groups of 64 bidders:
+// S_total = 2^k <= 64 waves per group (each scanning n/S_total targets); up to 16 of them live
+// in one workgroup (LDS merge), the rest in sibling workgroups (merge in emd_bid_finish_kernel).
+struct BidSplit {
+  int s_total, s_block, nb;
+};
+__host__ __device__ inline BidSplit bid_split(int ngroups, int G) {
+  int s = 1;
+  while (s < kMaxSegments && s * 2 * ngroups <= G * kBidWaves) s *= 2;
+  if (s > kBidWaves && ngroups > kMaxSplitGroups) s = kBidWaves;
+  BidSplit r;
+  r.s_total = s;
+  r.s_block = s < kBidWaves ? s : kBidWaves;
+  r.nb = s / r.s_block;
+  return r;
+}
+
+__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const Top2 &top,
+                                         float eps) {
+  const float inc = (top.best - top.better) + eps;
+  A.bid[o + j] = top.best_i;
+  A.bid2[o + j] = top.better_i == top.best_i ? -1 : top.better_i;
+  A.bid_inc[o + j] = inc;
+  atomic_max_float(&A.max_inc[o + top.best_i], inc);
+  A.max_idx[o + top.best_i] = -1;  // winner is re-derived by emd_getmax_kernel
+}
 
 // ---------------------------------------------------------------------------------------
 // Bid kernel.  Every lane of a wave is a DIFFERENT bidder and the whole wave walks the SAME
@@ -219,9 +255,6 @@ struct BidOut {
 // the device from the unassigned count so that the fixed grid stays busy when few bidders
 // are left (tail iterations), and is 1 while there are >= 64 * waves bidders.
 // ---------------------------------------------------------------------------------------
-constexpr int kBidWaves = 16;
-constexpr int kBidThreads = kBidWaves * 64;
-
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const float cfloat;
 typedef __attribute__((address_space(4))) const f4 cf4;
@@ -270,20 +303,23 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
   const cfloat *prc = uniform_ptr(price + o);
 
   const int ngroups = (U + 63) >> 6;
-  int S = 1;
-  while (S < kBidWaves && S * 2 * ngroups <= G * kBidWaves) S *= 2;
-  const int gpb = kBidWaves / S;   // bidder groups per workgroup
-  const int seg = wave & (S - 1);  // this wave's target segment
+  const BidSplit sp = bid_split(ngroups, G);
+  const int S = sp.s_block;        // segments (waves) of one group inside this workgroup
+  const int gpb = kBidWaves / S;   // bidder groups per workgroup (1 when the group is split)
+  const int seg = wave & (S - 1);  // this wave's segment within the workgroup
   const int gslot = wave / S;
-  const int seg_len = n / S;       // n % 1024 == 0, S <= 16: a multiple of 64
-  const int k_begin = seg * seg_len, k_end = k_begin + seg_len;
+  const int seg_len = n / sp.s_total;  // n % 1024 == 0, s_total <= 64: a multiple of 16
 
   // reference partition, only needed to order exact ties (emd_cuda.cu:108-109,136)
   const int block_cnt = n / 1024;
   const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
 
-  for (int g0 = bx * gpb; g0 < ngroups; g0 += G * gpb) {  // uniform per block
-    const int grp = g0 + gslot;
+  // work items: (group, part) with part < nb; a workgroup takes gpb consecutive groups (nb == 1)
+  // or one (group, part) (nb > 1)
+  for (int q0 = bx * gpb; q0 < ngroups * sp.nb; q0 += G * gpb) {  // uniform per block
+    const int grp = sp.nb > 1 ? q0 / sp.nb : q0 + gslot;
+    const int part = sp.nb > 1 ? q0 % sp.nb : 0;
+    const int k_begin = (part * S + seg) * seg_len, k_end = k_begin + seg_len;
     const int u = grp * 64 + lane;
     const bool active = grp < ngroups && u < U;
     const int j = lst[active ? u : 0];
@@ -302,7 +338,6 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
       }
     }
     float cthr = filter_thr(cm);
-    int n_slow_groups = 0, n_exact = 0;  // wave-uniform diagnostics (stats[2], stats[3])
 
     if (grp < ngroups) {  // wave-uniform
       // software pipelined: the next 4 targets' record pair (s_load_dwordx16) is in flight
@@ -328,11 +363,9 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         // evaluated with an older (looser) threshold only passes more, never less.
         if (__builtin_expect(__any(pass[0] | pass[1] | pass[2] | pass[3]), 0)) {
           const int ku = __builtin_amdgcn_readfirstlane(k);
-          ++n_slow_groups;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (__any(pass[i])) {
-              ++n_exact;
               const float d =
                   (float)((3.0 - (double)__builtin_sqrtf(sq[i])) - (double)prc[ku + i]);
               if (pass[i]) top2_push(top, d, ku + i, geom);
@@ -342,10 +375,6 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
           }
         }
       }
-    }
-    if (stats && lane == 0 && grp < ngroups) {
-      atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 2, (unsigned long long)n_slow_groups);
-      atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 3, (unsigned long long)n_exact);
     }
     // merge the S partial results of a bidder group (segment 0's wave collects)
     if (S > 1) {
@@ -359,15 +388,40 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
           top2_merge(top, m_best[w][lane], m_better[w][lane], m_bi[w][lane], m_bi2[w][lane], geom);
       __syncthreads();  // LDS merge slots are reused by the next group
     }
-    if (active && seg == 0) {
-      const float inc = (top.best - top.better) + eps;
-      A.bid[o + j] = top.best_i;
-      A.bid2[o + j] = top.better_i == top.best_i ? -1 : top.better_i;
-      A.bid_inc[o + j] = inc;
-      atomic_max_float(&A.max_inc[o + top.best_i], inc);
-      A.max_idx[o + top.best_i] = -1;  // winner is re-derived by emd_getmax_kernel
+    if (seg == 0 && grp < ngroups) {
+      if (sp.nb == 1) {
+        if (active) emit_bid(A, o, j, top, eps);
+      } else {  // publish this workgroup's partial; emd_bid_finish_kernel merges the nb of them
+        A.partial[(((size_t)b * kMaxSplitGroups + grp) * kMaxSplit + part) * 64 + lane] =
+            make_float4(top.best, top.better, __int_as_float(top.best_i), __int_as_float(top.better_i));
+      }
     }
   }
+}
+
+// merges the partial top-2's of bidder groups that were split over several workgroups
+__global__ __launch_bounds__(kBidThreads) void emd_bid_finish_kernel(
+    int G, int n, float eps, const int *__restrict__ list, const int *__restrict__ cnt, BidOut A) {
+  const int b = blockIdx.x;
+  const int U = cnt[b];
+  if (U == 0) return;
+  const int ngroups = (U + 63) >> 6;
+  const BidSplit sp = bid_split(ngroups, G);
+  if (sp.nb == 1) return;
+  const int grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u = grp * 64 + lane;
+  if (grp >= ngroups || u >= U) return;
+  const size_t o = (size_t)b * n;
+  const int block_cnt = n / 1024;
+  const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
+  const float4 *pp = A.partial + ((size_t)b * kMaxSplitGroups + grp) * kMaxSplit * 64 + lane;
+  const float4 p0 = pp[0];
+  Top2 top = {p0.x, p0.y, __float_as_int(p0.z), __float_as_int(p0.w)};
+  for (int q = 1; q < sp.nb; ++q) {
+    const float4 pq = pp[(size_t)q * 64];
+    top2_merge(top, pq.x, pq.y, __float_as_int(pq.z), __float_as_int(pq.w), geom);
+  }
+  emit_bid(A, o, list[o + u], top, eps);
 }
 
 __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
@@ -467,7 +521,8 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
   ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
   ws.cnt[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
-  ws.tgt = reinterpret_cast<float *>(p);
+  ws.tgt = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.partial = reinterpret_cast<float *>(p);
   return ws;
 }
 
@@ -476,7 +531,7 @@ EmdWs carve(void *workspace, int b, int n) {
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
   return 9 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
-         sn::align_up((size_t)b * n * 16, 256);
+         sn::align_up((size_t)b * n * 16, 256) + (size_t)b * 16 * 4 * 64 * 16;
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
@@ -495,14 +550,16 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
-  static const int g_env = getenv("SN_EMD_G") ? atoi(getenv("SN_EMD_G")) : kBlocksPerCloud;
+  const int g_env = kBlocksPerCloud;
   const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
   for (int it = 0; it < iters; ++it) {
     const int c = it & 1;
-    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx};
+    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx,
+                       reinterpret_cast<float4 *>(ws.partial)};
     SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
         b, g_env, n, eps, xyz1, xyz2, ws.price, ws.tgt, ws.list[c], ws.cnt[c], bo, stats)));
+    emd_bid_finish_kernel<<<b, kBidThreads, 0, s>>>(g_env, n, eps, ws.list[c], ws.cnt[c], bo);
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.cnt[c ^ 1]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,

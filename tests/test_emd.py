@@ -91,7 +91,7 @@ def test_host_wrapper_asserts_like_reference():
 def _hip(x, y, eps, iters, dev, stats=False):
     from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
 
-    st = torch.zeros(4, dtype=torch.int64, device=dev) if stats else None
+    st = torch.zeros(2, dtype=torch.int64, device=dev) if stats else None
     d, a = emd_forward_raw(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), eps, iters, st)
     out = (d.cpu().numpy(), a.cpu().numpy())
     return out + (st.cpu().numpy(),) if stats else out
@@ -174,7 +174,7 @@ def test_hip_full_size_properties(dev):
     y = torch.rand(32, 16384, 3, generator=g).to(dev)
     from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
 
-    st = torch.zeros(4, dtype=torch.int64, device=dev)
+    st = torch.zeros(2, dtype=torch.int64, device=dev)
     d, a = emd_forward_raw(x, y, 0.005, 50, st)
     assert int(a.min()) >= 0 and int(a.max()) < 16384
     sel = torch.gather(y, 1, a.long().unsqueeze(-1).expand(-1, -1, 3))

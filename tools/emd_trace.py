@@ -13,7 +13,7 @@ torch.cuda.synchronize()
 prev = 0
 out = []
 for it in (1, 2, 3, 5, 10, 20, 30, 40, 50):
-    st = torch.zeros(4, dtype=torch.int64, device=dev)
+    st = torch.zeros(2, dtype=torch.int64, device=dev)
     emd_forward_raw(x, y, 0.005, it, st)
     torch.cuda.synchronize()
     out.append((it, st[0].item() / N / B))

@@ -8,7 +8,7 @@ from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansi
 dev = torch.device("cuda:0")
 B, N = 32, 16384
 x = torch.rand(B, N, 3, device=dev); y = torch.rand(B, N, 3, device=dev)
-st = torch.zeros(4, dtype=torch.int64, device=dev)
+st = torch.zeros(2, dtype=torch.int64, device=dev)
 for it in (1, 50):
     emd_forward_raw(x, y, 0.005, it)
     torch.cuda.synchronize()
