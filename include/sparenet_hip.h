@@ -144,12 +144,17 @@ int sn_p2i_max_forward(const float *points, const float *feat,
                        float radius, float *out, int *out_ids, void *workspace,
                        size_t workspace_bytes, void *stream);
 /* points_grad[npoints,2], feat_grad[npoints,channels],
- * background_grad[batch,channels,h,w] are fully overwritten. */
+ * background_grad[batch,channels,h,w] are fully overwritten.
+ * batch_inds: the forward's batch_inds, or NULL (the reference's backward does not
+ * receive it; without it every image plane is searched for the point's wins). */
+size_t sn_p2i_max_backward_workspace_bytes(int batch, int channels, int h, int w);
 int sn_p2i_max_backward(const float *out_grad, const int *out_ids,
-                        const float *points, const float *feat, int npoints,
-                        int channels, int batch, int h, int w, float radius,
+                        const float *points, const float *feat,
+                        const int *batch_inds, int npoints, int channels,
+                        int batch, int h, int w, float radius,
                         float *points_grad, float *feat_grad,
-                        float *background_grad, void *stream);
+                        float *background_grad, void *workspace,
+                        size_t workspace_bytes, void *stream);
 /* replaces p2i_op.p2i_sum_forward_gpu / p2i_sum_backward_gpu
  *          (cuda/p2i_op/ext.cpp:6-7; p2i_sum.h:133-214; functors :7-131)
  * out must hold a copy of background on entry (the reference clones it,

@@ -52,6 +52,11 @@ __device__ __forceinline__ float cos_weight(float r, float radius) {
   return (float)(cos((double)r * M_PI / (double)radius) * 0.5 + 0.5);
 }
 
+__device__ __forceinline__ float sq2(float dx, float dy) {
+#pragma clang fp contract(off)
+  return dx * dx + dy * dy;
+}
+
 __device__ __forceinline__ float radius_of(float dx, float dy) {
 #pragma clang fp contract(off)
   return __builtin_sqrtf(dx * dx + dy * dy);
@@ -65,35 +70,157 @@ __global__ __launch_bounds__(256) void p2i_max_init_kernel(const float *__restri
     img[e] = ((unsigned long long)ord_f32(background[e]) << 32) | 0xFFFFFFFFull;
 }
 
+// ---------------------------------------------------------------------------------------
+// max splat.  Two ideas on top of the lock-free packed atomicMax:
+//  * dominance pruning: in a dense splat every pixel is hit by tens of points but only the
+//    running maximum matters.  A cheap fp32 upper bound of feature*weight (hardware cosine
+//    +- 2e-5) is compared with the pixel's CURRENT value, read with an L2-served relaxed
+//    atomic load (values only grow, so a stale read can only under-prune);
+//  * wave-level compaction: the few surviving hits (~5 %) are appended to a per-wave LDS queue
+//    (ballot + mbcnt) and drained 64 at a time, so the fp64 cosine and the 64-bit atomicMax
+//    run on full waves instead of on the 1-3 live lanes of a divergent branch.
+// ---------------------------------------------------------------------------------------
+// XCD-aware work map (speed only; results do not depend on it).  Workgroup g runs on XCD
+// g % 8.  The point list is cut in `batch` equal chunks -- in ComputeDepthMaps chunk i is
+// exactly image i -- and chunk i is handled by workgroups of XCD i % 8, so the 64-bit image
+// of one view (512 KB per 256x256 plane, 16.8 MB per batch of 32) is touched by ONE 4 MB L2
+// per plane instead of cycling through all eight.  Returns the point-group id or -1.
+__device__ __forceinline__ long xcd_point_group(int lpp, int npoints, int channels, int batch) {
+  const int gpb = 256 / lpp;                                   // groups per workgroup
+  const long chunk = ((long)npoints + batch - 1) / batch * channels;  // groups per chunk
+  const int bpc = (int)((chunk + gpb - 1) / gpb);              // workgroups per chunk
+  const int g = blockIdx.x, xcd = g & 7, r = g >> 3;
+  const int cidx = (r / bpc) * 8 + xcd;
+  if (cidx >= batch) return -1;
+  const long local = (long)(r % bpc) * gpb + threadIdx.x / lpp;
+  if (local >= chunk) return -1;
+  const long gid = (long)cidx * chunk + local;
+  return gid < (long)npoints * channels ? gid : -1;
+}
+inline long xcd_point_blocks(int lpp, int npoints, int channels, int batch) {
+  const int gpb = 256 / lpp;
+  const long chunk = ((long)npoints + batch - 1) / batch * channels;
+  const long bpc = (chunk + gpb - 1) / gpb;
+  return bpc * 8 * ((batch + 7) / 8);
+}
+
+struct SplatHit {
+  unsigned pix;    // pixel index inside the whole [B,C,H,W] image
+  float r, f;
+  unsigned low;    // 0xFFFFFFFE - point id
+};
+
+// largest fp32 s with sqrtf(s) <= radius (sqrtf correctly rounded and monotone), so that
+// "s <= s_max" decides exactly what the reference's "sqrt(dx*dx+dy*dy) <= radius" decides
+__device__ __forceinline__ float max_sq_inside(float radius) {
+#pragma clang fp contract(off)
+  float s = radius * radius;
+  while (__builtin_sqrtf(s) > radius) s = __uint_as_float(__float_as_uint(s) - 1u);
+  for (;;) {
+    const float t = __uint_as_float(__float_as_uint(s) + 1u);
+    if (!(__builtin_sqrtf(t) <= radius)) break;
+    s = t;
+  }
+  return s;
+}
+
+__device__ __forceinline__ void splat_exact(const SplatHit &hh, unsigned long long *img,
+                                            float radius) {
+  const float v = hh.f * cos_weight(__builtin_sqrtf(hh.r), radius);  // hh.r holds dx*dx+dy*dy
+  atomicMax(img + hh.pix, ((unsigned long long)ord_f32(v) << 32) | hh.low);
+}
+
 template <int LPP>
 __global__ __launch_bounds__(256) void p2i_max_splat_kernel(
     const float *__restrict__ points, const float *__restrict__ feat,
     const int *__restrict__ batch_inds, unsigned long long *__restrict__ img, int npoints,
     int channels, int batch, int h, int w, float radius) {
-  const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) / LPP;
+  constexpr int kQ = 128;
+  __shared__ SplatHit queue[4][kQ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  SplatHit *q = queue[wave];
+  const long gid = xcd_point_group(LPP, npoints, channels, batch);
   const int l = threadIdx.x % LPP;
-  if (gid >= (long)npoints * channels) return;
-  const int c = (int)(gid % channels);
-  const int pid = (int)((gid / channels) % npoints);
-  const int b = batch_inds[pid];
-  if (b < 0 || b >= batch) return;
-  const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
-  const float f = feat[gid];
-  const Box bx = box_of(py, px, h, w, radius);
-  const unsigned low = 0xFFFFFFFEu - (unsigned)pid;
-  unsigned long long *plane = img + ((size_t)b * channels + c) * h * w;
-  for (int x = bx.min_x + l; x <= bx.max_x; x += LPP) {
+  bool alive = gid >= 0;
+  int x = 0, y = 0, min_y = 0, max_y = -1, max_x = -1;
+  float px = 0.f, py = 0.f, f = 0.f;
+  unsigned low = 0, plane = 0;
+  if (alive) {
+    const int c = (int)(gid % channels);
+    const int pid = (int)((gid / channels) % npoints);
+    const int b = batch_inds[pid];
+    if (b < 0 || b >= batch) {
+      alive = false;
+    } else {
+      py = points[pid * 2 + 0];
+      px = points[pid * 2 + 1];
+      f = feat[gid];
+      const Box bx = box_of(py, px, h, w, radius);
+      x = bx.min_x + l;
+      y = min_y = bx.min_y;
+      max_y = bx.max_y;
+      max_x = bx.max_x;
+      low = 0xFFFFFFFEu - (unsigned)pid;
+      plane = (unsigned)(((size_t)b * channels + c) * h * w);
+      alive = x <= max_x;
+    }
+  }
+  const float rev_scale = 0.5f / radius;  // r*pi/R radians = r/(2R) revolutions
+  const float s_max = max_sq_inside(radius);
+  int qn = 0;                             // wave-uniform queue fill
+  constexpr int kRows = 8;                // rows of one column handled per trip: 8 independent
+                                          // L2 reads in flight instead of one dependent read
+  while (__any(alive)) {
+    float s2[kRows];
+    unsigned pix[kRows], cur[kRows];
+    bool in[kRows];
     const float dx = x - px;
-    for (int y = bx.min_y; y <= bx.max_y; ++y) {
-      const float dy = y - py;
-      const float r = radius_of(dx, dy);
-      if (r <= radius) {
-        const float v = f * cos_weight(r, radius);
-        const unsigned long long key = ((unsigned long long)ord_f32(v) << 32) | low;
-        atomicMax(plane + (size_t)y * w + x, key);
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      const int yy = y + i;
+      s2[i] = sq2(dx, yy - py);
+      in[i] = alive && yy <= max_y && s2[i] <= s_max;  // <=> sqrtf(s2) <= radius
+      pix[i] = in[i] ? plane + (unsigned)yy * w + x : plane;
+    }
+#pragma unroll
+    for (int i = 0; i < kRows; ++i)
+      cur[i] = (unsigned)(__hip_atomic_load(img + pix[i], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT) >> 32);
+#pragma unroll
+    for (int i = 0; i < kRows; ++i) {
+      bool pass = false;
+      if (in[i]) {
+        const float ra = __builtin_amdgcn_sqrtf(s2[i]);  // ~1 ulp: only feeds the bound
+        const float wq = __builtin_amdgcn_cosf(ra * rev_scale) * 0.5f + 0.5f;
+        const float ub = f >= 0.f ? f * (wq + 2e-5f) : f * __builtin_fmaxf(wq - 2e-5f, 0.f);
+        pass = !(ord_f32(ub) < cur[i]);  // can still reach (or tie with) the current value
+      }
+      const unsigned long long m = __ballot(pass);
+      if (m) {
+        if (pass)
+          q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+              SplatHit{pix[i], s2[i], f, low};  // exact r is recomputed on the exact path
+        qn += __popcll(m);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        if (qn >= 64) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          qn -= 64;
+          splat_exact(q[qn + lane], img, radius);
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+      }
+    }
+    if (alive) {
+      y += kRows;
+      if (y > max_y) {
+        y = min_y;
+        x += LPP;
+        alive = x <= max_x;
       }
     }
   }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (lane < qn) splat_exact(q[lane], img, radius);
 }
 
 __global__ __launch_bounds__(256) void p2i_max_finalize_kernel(
@@ -108,34 +235,108 @@ __global__ __launch_bounds__(256) void p2i_max_finalize_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void p2i_max_bwd_kernel(
+// ---------------------------------------------------------------------------------------
+// max backward in two dense passes, no atomics.
+// The reference walks the pixels and scatters into the winning point with three fp32 atomics
+// per pixel (device-scope atomics leave the XCD on MI355X and serialise on popular points).
+//   pass 1 (per pixel, fully dense): the fp64 sine/cosine terms of every pixel that has a
+//           winner -> three per-pixel contribution planes (d feature, d row, d col);
+//           background_grad on the side.
+//   pass 2 (per point, gather): a point walks its own footprint (the forward's pixel walk,
+//           LPP lanes per point), sums the contributions of the pixels it won
+//           (out_ids == point id) in a fixed order and writes its gradient once.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p2i_max_bwd_pixels_kernel(
     const float *__restrict__ out_grad, const int *__restrict__ out_ids,
     const float *__restrict__ points, const float *__restrict__ feat,
-    float *__restrict__ points_grad, float *__restrict__ feat_grad,
-    float *__restrict__ background_grad, int channels, int h, int w, float radius, long total) {
+    float *__restrict__ background_grad, float *__restrict__ contrib, int channels, int h, int w,
+    float radius, long total) {
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
-    const int x = (int)(e % w), y = (int)((e / w) % h);
-    const int c = (int)((e / ((long)w * h)) % channels);
     const float g = out_grad[e];
     const int pid = out_ids[e];
-    if (pid < 0) {
-      background_grad[e] = g;
-      continue;
+    float cf = 0.f, cy = 0.f, cx = 0.f;
+    if (pid >= 0) {
+      const int x = (int)(e % w), y = (int)((e / w) % h);
+      const int c = (int)((e / ((long)w * h)) % channels);
+      const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+      const float dx = x - px, dy = y - py;
+      const float r = radius_of(dx, dy);
+      const float wgt = cos_weight(r, radius);
+      const float fv = feat[(size_t)pid * channels + c];
+      cf = g * wgt;
+      const float wg = g * fv;
+      const float rm = r > 1e-10f ? r : 1e-10f;
+      const float k = (float)((double)wg * sin((double)r * M_PI / (double)radius) * 0.5 * M_PI /
+                              (double)radius / (double)rm);
+      cy = k * dy;
+      cx = k * dx;
     }
-    background_grad[e] = 0.f;
-    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
-    const float dx = x - px, dy = y - py;
-    const float r = radius_of(dx, dy);
-    const float wgt = cos_weight(r, radius);
-    const float fv = feat[(size_t)pid * channels + c];
-    unsafeAtomicAdd(&feat_grad[(size_t)pid * channels + c], g * wgt);
-    const float wg = g * fv;
-    const float rm = r > 1e-10f ? r : 1e-10f;
-    const float k = (float)((double)wg * sin((double)r * M_PI / (double)radius) * 0.5 * M_PI /
-                            (double)radius / (double)rm);
-    unsafeAtomicAdd(&points_grad[pid * 2 + 0], k * dy);
-    unsafeAtomicAdd(&points_grad[pid * 2 + 1], k * dx);
+    background_grad[e] = pid < 0 ? g : 0.f;
+    contrib[e] = cf;
+    contrib[total + e] = cy;
+    contrib[2 * total + e] = cx;
+  }
+}
+
+template <int LPP>
+__global__ __launch_bounds__(256) void p2i_max_bwd_points_kernel(
+    const int *__restrict__ out_ids, const float *__restrict__ contrib,
+    const float *__restrict__ points, const int *__restrict__ batch_inds,
+    float *__restrict__ points_grad, float *__restrict__ feat_grad, int npoints, int channels,
+    int batch, int h, int w, float radius, long total) {
+  // thread group = one point; channels are walked inside (points_grad sums over channels)
+  const long gid = xcd_point_group(LPP, npoints, 1, batch);
+  const int l = threadIdx.x % LPP;
+  if (gid < 0) return;
+  const int pid = (int)gid;
+  const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+  const Box bx = box_of(py, px, h, w, radius);
+  const float s_max = max_sq_inside(radius);
+  // with batch_inds the point's image is known; without (the reference's backward does not
+  // receive it) every image plane is searched -- a point id is unique across the batch
+  const int bi = batch_inds ? batch_inds[pid] : -1;
+  const int b_lo = batch_inds ? bi : 0, b_hi = batch_inds ? bi + 1 : batch;
+  float gy = 0.f, gx = 0.f;
+  for (int c = 0; c < channels; ++c) {
+    float gf = 0.f;
+    for (int b = b_lo; b < b_hi; ++b) {
+      if (b < 0 || b >= batch) continue;
+      const size_t plane = ((size_t)b * channels + c) * h * w;
+      for (int x = bx.min_x + l; x <= bx.max_x; x += LPP) {
+        const float dx = x - px;
+        for (int y0 = bx.min_y; y0 <= bx.max_y; y0 += 8) {
+          int ids[8];
+          bool in[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {  // 8 independent id reads in flight
+            const int yy = y0 + i;
+            in[i] = yy <= bx.max_y && sq2(dx, yy - py) <= s_max;
+            ids[i] = out_ids[plane + (size_t)(in[i] ? yy : y0) * w + x];
+          }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (!in[i] || ids[i] != pid) continue;
+            const size_t e = plane + (size_t)(y0 + i) * w + x;
+            gf += contrib[e];
+            gy += contrib[total + e];
+            gx += contrib[2 * total + e];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < LPP; m <<= 1) gf += __shfl_xor(gf, m, LPP);
+    if (l == 0) feat_grad[(size_t)pid * channels + c] = gf;
+  }
+#pragma unroll
+  for (int m = 1; m < LPP; m <<= 1) {
+    gy += __shfl_xor(gy, m, LPP);
+    gx += __shfl_xor(gx, m, LPP);
+  }
+  if (l == 0) {
+    points_grad[pid * 2 + 0] = gy;
+    points_grad[pid * 2 + 1] = gx;
   }
 }
 
@@ -223,7 +424,7 @@ int check_common(const char *fn, int npoints, int channels, int batch, int h, in
     return sn::fail(SN_EINVAL, "%s: bad sizes npoints=%d channels=%d batch=%d h=%d w=%d", fn,
                     npoints, channels, batch, h, w);
   if (!(radius > 0.f)) return sn::fail(SN_EINVAL, "%s: kernel radius must be > 0", fn);
-  if ((long)batch * channels * h * w >= (1L << 31) || (long)npoints * channels >= (1L << 31))
+  if ((long)batch * channels * h * w >= (1L << 31) - 1 || (long)npoints * channels >= (1L << 31))
     return sn::fail(SN_EINVAL, "%s: tensor too large", fn);
   return 0;
 }
@@ -256,7 +457,7 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
   const long groups = (long)npoints * channels;
   if (groups > 0) {
     const int lpp = lanes_per_point(radius);
-    const long blocks = (groups * lpp + 255) / 256;
+    const long blocks = xcd_point_blocks(lpp, npoints, channels, batch);
     SN_REQUIRE(blocks < (1L << 31), "sn_p2i_max_forward: too many points");
 #define SN_SPLAT(L)                                                                          \
   p2i_max_splat_kernel<L><<<(int)blocks, 256, 0, s>>>(points, feat, batch_inds, img, npoints, \
@@ -276,23 +477,43 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
   return sn::launch_status("sn_p2i_max_forward");
 }
 
+extern "C" size_t sn_p2i_max_backward_workspace_bytes(int batch, int channels, int h, int w) {
+  if (batch < 1 || channels < 1 || h < 1 || w < 1) return 0;
+  return (size_t)batch * channels * h * w * 12;
+}
+
 extern "C" int sn_p2i_max_backward(const float *out_grad, const int *out_ids, const float *points,
-                                   const float *feat, int npoints, int channels, int batch, int h,
-                                   int w, float radius, float *points_grad, float *feat_grad,
-                                   float *background_grad, void *stream) {
-  SN_REQUIRE(out_grad && out_ids && background_grad, "sn_p2i_max_backward: null pointer");
+                                   const float *feat, const int *batch_inds, int npoints,
+                                   int channels, int batch, int h, int w, float radius,
+                                   float *points_grad, float *feat_grad, float *background_grad,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(out_grad && out_ids && background_grad && workspace, "sn_p2i_max_backward: null pointer");
   SN_REQUIRE(npoints == 0 || (points && feat && points_grad && feat_grad),
              "sn_p2i_max_backward: null pointer");
   if (int rc = check_common("sn_p2i_max_backward", npoints, channels, batch, h, w, radius)) return rc;
+  SN_REQUIRE(workspace_bytes >= sn_p2i_max_backward_workspace_bytes(batch, channels, h, w),
+             "sn_p2i_max_backward: workspace too small");
   hipStream_t s = sn::as_stream(stream);
-  if (npoints > 0) {
-    SN_HIP(hipMemsetAsync(points_grad, 0, (size_t)npoints * 2 * 4, s));
-    SN_HIP(hipMemsetAsync(feat_grad, 0, (size_t)npoints * channels * 4, s));
-  }
   const long px = (long)batch * channels * h * w;
-  p2i_max_bwd_kernel<<<lin_blocks(px), 256, 0, s>>>(out_grad, out_ids, points, feat, points_grad,
-                                                    feat_grad, background_grad, channels, h, w,
-                                                    radius, px);
+  float *contrib = static_cast<float *>(workspace);
+  p2i_max_bwd_pixels_kernel<<<lin_blocks(px), 256, 0, s>>>(out_grad, out_ids, points, feat,
+                                                           background_grad, contrib, channels, h, w,
+                                                           radius, px);
+  if (npoints > 0) {
+    const int lpp = lanes_per_point(radius);
+    const long blocks = xcd_point_blocks(lpp, npoints, 1, batch);
+#define SN_BWD(L)                                                                            \
+  p2i_max_bwd_points_kernel<L><<<(int)blocks, 256, 0, s>>>(out_ids, contrib, points, batch_inds, \
+      points_grad, feat_grad, npoints, channels, batch, h, w, radius, px)
+    switch (lpp) {
+      case 4: SN_BWD(4); break;
+      case 8: SN_BWD(8); break;
+      case 16: SN_BWD(16); break;
+      case 32: SN_BWD(32); break;
+      default: SN_BWD(64); break;
+    }
+#undef SN_BWD
+  }
   return sn::launch_status("sn_p2i_max_backward");
 }
 

@@ -50,7 +50,7 @@ class _Ext:
 
     @staticmethod
     def p2i_max_backward_gpu(out_grad, out_point_ids, points, point_features, kernel_kind,
-                             kernel_radius):
+                             kernel_radius, batch_inds=None):
         n = points.size(0)
         c = point_features.size(1)
         b, _, h, w = out_grad.shape
@@ -58,12 +58,15 @@ class _Ext:
         feat_grad = torch.empty_like(point_features)
         bg_grad = torch.empty_like(out_grad)
         with torch.cuda.device_of(out_grad):
+            nbytes = _lib.lib().sn_p2i_max_backward_workspace_bytes(b, c, h, w)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=out_grad.device)
             code = _lib.lib().sn_p2i_max_backward(
                 _lib.fptr(out_grad, "out_grad"), _lib.iptr(out_point_ids, "out_point_ids"),
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
+                _lib.iptr(batch_inds, "batch_inds") if batch_inds is not None else ctypes.c_void_p(0),
                 n, c, b, h, w, _lib.cfloat(kernel_radius), _lib.fptr(points_grad, "points_grad"),
                 _lib.fptr(feat_grad, "point_features_grad"), _lib.fptr(bg_grad, "background_grad"),
-                _lib.stream_of(out_grad))
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(out_grad))
         _lib.check(code, "sn_p2i_max_backward")
         return points_grad, feat_grad, bg_grad
 
@@ -134,15 +137,16 @@ class P2IMaxFunction(Function):
     def forward(ctx, points, point_features, batch_inds, background, kernel_kind, kernel_radius):
         out, winner_ids = ext.p2i_max_forward_gpu(
             *_c(points, point_features, batch_inds, background), kernel_kind, kernel_radius)
-        ctx.save_for_backward(points, point_features, winner_ids)
+        ctx.save_for_backward(points, point_features, winner_ids, batch_inds.contiguous())
         ctx.kind_radius = (kernel_kind, kernel_radius)
         return out
 
     @staticmethod
     def backward(ctx, out_grad):
-        points, point_features, winner_ids = ctx.saved_tensors
+        points, point_features, winner_ids, batch_inds = ctx.saved_tensors
         g_points, g_feat, g_bg = ext.p2i_max_backward_gpu(
-            out_grad.contiguous(), winner_ids, *_c(points, point_features), *ctx.kind_radius)
+            out_grad.contiguous(), winner_ids, *_c(points, point_features), *ctx.kind_radius,
+            batch_inds=batch_inds)
         return g_points, g_feat, None, g_bg, None, None
 
 
