@@ -152,7 +152,7 @@ def cpu_baseline():
     g = torch.Generator().manual_seed(1234)
     pred = torch.rand(B, N, 3, generator=g).numpy()
     gt = torch.rand(B, N, 3, generator=g).numpy()
-    nb_cd, nb_emd = 8, 1
+    nb_cd, nb_emd, nb_p2i = 32, 16, 32   # sized for ~10-30 s of CPU work on a 2-socket host
     t0 = time.perf_counter()
     oracle.chamfer_forward(pred[:nb_cd], gt[:nb_cd], mt=True)
     t_cd = time.perf_counter() - t0
@@ -165,12 +165,12 @@ def cpu_baseline():
     # render sample: one view, one radius, 4 clouds, through the oracle p2i (single thread)
     from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
     cdm = ComputeDepthMaps("orthorgonal", 1.0, IMG)
-    data = torch.from_numpy(pred[:4]) - 0.5
+    data = torch.from_numpy(pred[:nb_p2i]) - 0.5
     ij, feat = cdm.project(data, 0)
     px = ((ij + 1) / 2 * (IMG - 1)).numpy()
-    bi = np.repeat(np.arange(4, dtype=np.int32), N)
+    bi = np.repeat(np.arange(nb_p2i, dtype=np.int32), N)
     t0 = time.perf_counter()
-    oracle.p2i_max_forward(px, feat.numpy(), bi, np.zeros((4, 1, IMG, IMG), np.float32), 5.0)
+    oracle.p2i_max_forward(px, feat.numpy(), bi, np.zeros((nb_p2i, 1, IMG, IMG), np.float32), 5.0)
     t_p2i = time.perf_counter() - t0
     return {
         "value": (pairs_cd + pairs_emd) / (t_cd + t_emd),
@@ -180,8 +180,8 @@ def cpu_baseline():
         "sample": (f"oracle (C, OpenMP x{cores} threads): Chamfer fwd on {nb_cd} of 32 clouds "
                    f"({pairs_cd:.3g} pairs, {t_cd:.2f} s) + EMD fwd eps {EMD_EPS} iters {EMD_ITERS} on "
                    f"{nb_emd} cloud ({pairs_emd:.3g} effective pairs, {t_emd:.2f} s); "
-                   f"p2i max fwd R=5 on 4 clouds x 1 view, 1 thread: {t_p2i:.2f} s"),
-        "depthmaps_per_sec_1thread": 4.0 / t_p2i,
+                   f"p2i max fwd R=5 on {nb_p2i} clouds x 1 view, 1 thread: {t_p2i:.2f} s"),
+        "depthmaps_per_sec_1thread": nb_p2i / t_p2i,
         "chamfer_pairs_per_sec": pairs_cd / t_cd,
         "emd_pairs_per_sec": pairs_emd / t_emd,
     }

@@ -53,12 +53,12 @@ __device__ __forceinline__ float bid_value(float tx, float ty, float tz, float p
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-// two targets at once; identical rounding to sq_dist, component-wise
-__device__ __forceinline__ f2 sq_dist2(f2 tx, f2 ty, f2 tz, float x1, float y1, float z1) {
-#pragma clang fp contract(off)
+// FILTER-ONLY squared distance of two targets at once: fused multiply-adds (6 packed ops
+// instead of 8).  It differs from the exact (dx*dx + dy*dy) + dz*dz by <= 2 ulp, which the
+// filter margins absorb; every target that passes is re-evaluated exactly by sq_dist.
+__device__ __forceinline__ f2 sq_dist2_fast(f2 tx, f2 ty, f2 tz, float x1, float y1, float z1) {
   const f2 dx = tx - x1, dy = ty - y1, dz = tz - z1;
-  const f2 xx = dx * dx, yy = dy * dy, zz = dz * dz;
-  return (xx + yy) + zz;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 }
 
 __device__ __forceinline__ float sq_dist(float tx, float ty, float tz, float x1, float y1,
@@ -129,7 +129,8 @@ __device__ __forceinline__ void top2_merge(Top2 &a, float b_best, float b_better
 //   =>  s < R^2 (1 + 2^-22).
 // The filter evaluates R' = A'_k - c' in fp32 with A'_k = fl(3 - p_k) + eps (3 + |p_k|) and
 // c' = c - eps (3 + |c|), eps = 2^-20: the two margins exceed every rounding error of the
-// filter itself (<= 2^-22 (6 + |p| + |c|)) and the relative slack needed on R, so
+// filter itself (<= 2^-22 (6 + |p| + |c|), plus 2^-22 relative on the FMA-evaluated s) and
+// the relative slack needed on R, so
 // "s <= R' |R'|" is implied by d_k >= c.  Only targets that pass go through the exact
 // path (correctly rounded sqrt, fp64 detour, top-2 update); everything else costs
 // 8 (distance) + 3 (filter) VALU ops instead of ~45.
@@ -351,13 +352,12 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         n1 = rec[1];
         n2 = rec[2];
         n3 = rec[3];
-        const f2 s01 = sq_dist2(f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, x1, y1, z1);
-        const f2 s23 = sq_dist2(f2{c2.x, c2.y}, f2{c2.z, c2.w}, f2{c3.x, c3.y}, x1, y1, z1);
+        const f2 s01 = sq_dist2_fast(f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, x1, y1, z1);
+        const f2 s23 = sq_dist2_fast(f2{c2.x, c2.y}, f2{c2.z, c2.w}, f2{c3.x, c3.y}, x1, y1, z1);
         const f2 r01 = f2{c1.z, c1.w} - cthr, r23 = f2{c3.z, c3.w} - cthr;
         // s <= R |R|: a negative R (target too expensive to matter at any distance) never passes
         const float t0 = r01.x * __builtin_fabsf(r01.x), t1 = r01.y * __builtin_fabsf(r01.y);
         const float t2 = r23.x * __builtin_fabsf(r23.x), t3 = r23.y * __builtin_fabsf(r23.y);
-        const float sq[4] = {s01.x, s01.y, s23.x, s23.y};
         const bool pass[4] = {s01.x <= t0, s01.y <= t1, s23.x <= t2, s23.y <= t3};
         // one wave-uniform branch per 4 targets; the exact path is out of line.  A filter
         // evaluated with an older (looser) threshold only passes more, never less.
@@ -366,8 +366,10 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             if (__any(pass[i])) {
-              const float d =
-                  (float)((3.0 - (double)__builtin_sqrtf(sq[i])) - (double)prc[ku + i]);
+              // exact re-evaluation (separately rounded products and sums) from the stream
+              const cfloat *rr = tg + (size_t)((ku + i) >> 1) * 8 + ((ku + i) & 1);
+              const float sq = sq_dist(rr[0], rr[2], rr[4], x1, y1, z1);
+              const float d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)prc[ku + i]);
               if (pass[i]) top2_push(top, d, ku + i, geom);
               cm = __builtin_fmaxf(cm, top.better);
               cthr = filter_thr(cm);
