@@ -411,11 +411,23 @@ __global__ __launch_bounds__(256) void p2i_sum_bwd_kernel(
   }
 }
 
+// lanes that share one point's footprint (box at most ceil(2R)+2 pixels wide; a lane walks
+// columns l, l+LPP, ...).  Forward: one pass, LPP = 2^k >= width -- the lanes of a point then
+// hit consecutive pixels of a row with their loads / atomics.  Backward gather: 8 lanes and
+// several passes waste the fewest lanes (R=10: 22 columns = 3 passes of 8, 92 % busy); measured
+// 0.14 ms vs 0.19 ms per call, while the forward is 10 % slower with 8.
 int lanes_per_point(float radius) {
-  const int width = (int)(2.f * (radius > 0.f ? radius : 0.f)) + 3;
+  const int width = (int)ceilf(2.f * (radius > 0.f ? radius : 0.f)) + 2;
   int l = 4;
   while (l < width && l < 64) l *= 2;
   return l;
+}
+int lanes_per_point_gather(float radius) {
+  const int width = (int)ceilf(2.f * (radius > 0.f ? radius : 0.f)) + 2;
+  if (width <= 4) return 4;
+  if (width <= 48) return 8;
+  if (width <= 128) return 16;
+  return 64;
 }
 
 int check_common(const char *fn, int npoints, int channels, int batch, int h, int w,
@@ -500,7 +512,7 @@ extern "C" int sn_p2i_max_backward(const float *out_grad, const int *out_ids, co
                                                            background_grad, contrib, channels, h, w,
                                                            radius, px);
   if (npoints > 0) {
-    const int lpp = lanes_per_point(radius);
+    const int lpp = lanes_per_point_gather(radius);
     const long blocks = xcd_point_blocks(lpp, npoints, 1, batch);
 #define SN_BWD(L)                                                                            \
   p2i_max_bwd_points_kernel<L><<<(int)blocks, 256, 0, s>>>(out_ids, contrib, points, batch_inds, \
