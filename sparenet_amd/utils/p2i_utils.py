@@ -19,7 +19,7 @@ import math
 
 import torch
 
-from sparenet_amd.cuda.p2i_op import p2i
+from sparenet_amd.cuda.p2i_op import P2IMaxFunction, p2i  # noqa: F401
 
 N_VIEWS_PREDEFINED = 8
 
@@ -117,7 +117,17 @@ class ComputeDepthMaps(torch.nn.Module):
         # [8,4,4]; a real buffer, so .to(device) moves all views once (the reference keeps a
         # Python list of CPU matrices and copies one to the device on every call, :208,:217)
         self.register_buffer("pre_matrices", torch.stack(mats), persistent=False)
+        self.register_buffer("_extent", torch.tensor([[image_size - 1.0, image_size - 1.0]], **f32),
+                             persistent=False)
         self.pre_matrix_list = [m.unsqueeze(0) for m in mats]
+        self._batch_inds_cache = {}
+
+    def _batch_inds(self, batch, npoints, device):
+        key = (batch, npoints, str(device))
+        if key not in self._batch_inds_cache:
+            self._batch_inds_cache = {key: torch.arange(batch, dtype=torch.int32, device=device)
+                                      .repeat_interleave(npoints)}
+        return self._batch_inds_cache[key]
 
     def project(self, data, view_id):
         """data [B,N,3] -> (pos_ijs [B*N,2], point_features [B*N,1]) exactly as the reference
@@ -137,8 +147,11 @@ class ComputeDepthMaps(torch.nn.Module):
         pos_ijs, point_features = self.project(data, view_id)
         background = torch.zeros(batch, 1, self.image_size, self.image_size, dtype=data.dtype,
                                  device=data.device)
-        batch_inds = torch.arange(batch, dtype=torch.int32, device=data.device)
-        batch_inds = batch_inds.repeat_interleave(npoints)
-        maps = [p2i(pos_ijs, point_features, batch_inds, background, kernel_radius=r,
-                    kernel_kind_str="cos", reduce="max") for r in radius_list]
+        batch_inds = self._batch_inds(batch, npoints, data.device)
+        # the reference calls p2i() once per radius (:230-251); the NDC -> pixel rescale that p2i()
+        # performs (cuda/p2i_op/__init__.py:117-121) and the zero background do not depend on the
+        # radius, so they are hoisted -- same operations, same values, a third of the launches
+        pixel_ijs = (pos_ijs + 1) / 2 * self._extent.to(device=data.device, dtype=data.dtype)
+        maps = [P2IMaxFunction.apply(pixel_ijs, point_features, batch_inds, background, 0, r)
+                for r in radius_list]
         return maps[0] if len(maps) == 1 else torch.cat(maps, dim=1)
