@@ -42,10 +42,12 @@ class expansionPenaltyFunction(Function):
 
     @staticmethod
     def backward(ctx, grad_dist, grad_idx, grad_mml):
+        # only `dist` carries a gradient; mean_mst_length is treated as a constant, as in the
+        # reference (expansion_penalty_module.py:42-48)
         xyz, assignment = ctx.saved_tensors
         grad_dist = grad_dist.contiguous().float()
-        grad_xyz = torch.empty_like(xyz)
         b, n, _ = xyz.shape
+        grad_xyz = torch.empty_like(xyz)
         with torch.cuda.device_of(xyz):
             code = _lib.lib().sn_expansion_backward(
                 _lib.fptr(xyz, "xyz"), _lib.fptr(grad_dist, "grad_dist"),
@@ -56,8 +58,9 @@ class expansionPenaltyFunction(Function):
 
 
 class expansionPenaltyModule(nn.Module):
-    def __init__(self):
-        super(expansionPenaltyModule, self).__init__()
+    """nn.Module face of expansionPenaltyFunction (the generator instantiates it once and
+    calls it per refinement stage, models/sparenet_generator.py:551,559)."""
 
     def forward(self, input, primitive_size, alpha):
-        return expansionPenaltyFunction.apply(input, primitive_size, alpha)
+        dist, assignment, mean_mst_length = expansionPenaltyFunction.apply(input, primitive_size, alpha)
+        return dist, assignment, mean_mst_length

@@ -48,17 +48,20 @@ class GriddingFunction(torch.autograd.Function):
 
 
 class Gridding(torch.nn.Module):
+    """ptcloud [B,n,3] in [-1,1) -> occupancy grid [B, scale^3].  Rows whose coordinates sum
+    to zero are padding and are dropped per sample, so samples are gridded one by one."""
+
     def __init__(self, scale=1):
-        super(Gridding, self).__init__()
-        self.scale = scale // 2
+        super().__init__()
+        self.scale = scale // 2          # half extent: vertices span [-scale/2, scale/2 - 1]
 
     def forward(self, ptcloud):
-        ptcloud = ptcloud * self.scale
-        grids = []
-        for p in torch.split(ptcloud, 1, dim=0):
-            keep = torch.sum(p, dim=2).ne(0)        # drop zero-padded points
-            grids.append(GriddingFunction.apply(self.scale, p[keep].unsqueeze(dim=0)))
-        return torch.cat(grids, dim=0).contiguous()
+        half = self.scale
+        per_sample = []
+        for cloud in (ptcloud * half).unbind(dim=0):          # [n,3] each
+            real = cloud[cloud.sum(dim=1).ne(0)]              # zero rows = padding
+            per_sample.append(GriddingFunction.apply(half, real.unsqueeze(0)))
+        return torch.cat(per_sample, dim=0).contiguous()
 
 
 class GriddingReverseFunction(torch.autograd.Function):
@@ -93,10 +96,12 @@ class GriddingReverseFunction(torch.autograd.Function):
 
 
 class GriddingReverse(torch.nn.Module):
+    """grid [B,s,s,s] -> one point per interior vertex [B, s^3, 3], rescaled to [-1,1)."""
+
     def __init__(self, scale=1):
-        super(GriddingReverse, self).__init__()
+        super().__init__()
         self.scale = scale
 
     def forward(self, grid):
-        ptcloud = GriddingReverseFunction.apply(self.scale, grid)
-        return ptcloud / self.scale * 2
+        vertex_space = GriddingReverseFunction.apply(self.scale, grid)
+        return vertex_space / self.scale * 2
