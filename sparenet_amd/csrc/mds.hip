@@ -137,6 +137,295 @@ __global__ __launch_bounds__(1024) void mds_kernel(int n, int m, const float *__
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Cluster-sorted variant (the production path for 2048 <= n <= 20352, e.g. SpareNet's 19384).
+// exp(-d/t) is EXACTLY 0 (sn_expf) once d/t >= 104, i.e. outside a ball of radius
+// sqrt(104 t) around the last pick (0.19 for SpareNet's t): there the update is a no-op.
+// With the reference's ownership (lane tid owns k = tid, tid+1024, ...) every register slot
+// of a wave mixes points from all over the cloud, so nothing can be skipped in SIMD.  Here
+// the points are first put in Morton order; slot i of wave w holds the 64 spatially adjacent
+// points of cluster i*16+w.  Every round one lane per slot tests the cluster's bounding
+// sphere against the ball (one ballot), and only the 1-3 slots that can receive a non-zero
+// update are evaluated; the others keep their densities untouched -- bit-identical results,
+// ~4x fewer issued ops per round.  The arg-min is order independent: every candidate carries
+// the key (density bits, bitrev(k mod 1024), k) of its ORIGINAL index k.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+
+// minimum over each row of 16 lanes, left in every lane of the row (four DPP steps)
+__device__ __forceinline__ unsigned row_min_u32(unsigned v) {
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));  // row_mirror
+  return v;
+}
+
+// wave-uniform minimum over the 64 lanes
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = row_min_u32(v);
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return umin32(umin32(a, b), umin32(c, d));
+}
+
+constexpr int kMdsCells = 4096;  // 16^3 Morton cells for the counting sort
+
+__device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigned z) {
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r |= (((x >> i) & 1u) << (3 * i)) | (((y >> i) & 1u) << (3 * i + 1)) | (((z >> i) & 1u) << (3 * i + 2));
+  return r;
+}
+
+// per cloud: bounding box -> cell histogram (one workgroup per cloud)
+__global__ __launch_bounds__(1024) void mds_sort_count_kernel(int n, const float *__restrict__ xyz,
+                                                              float *__restrict__ bbox,
+                                                              int *__restrict__ hist,
+                                                              int *__restrict__ cell_of) {
+  __shared__ float red[6][16];
+  __shared__ int lh[kMdsCells];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float *p = xyz + (size_t)b * n * 3;
+  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+  for (int k = tid; k < n; k += 1024)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = p[k * 3 + a];
+      lo[a] = __builtin_fminf(lo[a], v);
+      hi[a] = __builtin_fmaxf(hi[a], v);
+    }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int m = 1; m < 64; m <<= 1) {
+      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], m));
+      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], m));
+    }
+  if ((tid & 63) == 0)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      red[a][tid >> 6] = lo[a];
+      red[3 + a][tid >> 6] = hi[a];
+    }
+  for (int c = tid; c < kMdsCells; c += 1024) lh[c] = 0;
+  __syncthreads();
+  float blo[3], scale[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    float l = red[a][0], h = red[3 + a][0];
+    for (int w = 1; w < 16; ++w) {
+      l = __builtin_fminf(l, red[a][w]);
+      h = __builtin_fmaxf(h, red[3 + a][w]);
+    }
+    blo[a] = l;
+    scale[a] = h > l ? 15.999f / (h - l) : 0.f;
+    if (tid == 0) {
+      bbox[b * 6 + a] = l;
+      bbox[b * 6 + 3 + a] = h;
+    }
+  }
+  for (int k = tid; k < n; k += 1024) {
+    unsigned q[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float f = (p[k * 3 + a] - blo[a]) * scale[a];
+      q[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
+    }
+    const int c = (int)morton3_4bit(q[0], q[1], q[2]);
+    cell_of[(size_t)b * n + k] = c;
+    atomicAdd(&lh[c], 1);
+  }
+  __syncthreads();
+  // exclusive scan of the 4096 cell counts (4 per lane) -> start offsets
+  const int c0 = tid * 4;
+  const int v0 = lh[c0], v1 = lh[c0 + 1], v2 = lh[c0 + 2], v3 = lh[c0 + 3];
+  int sum = v0 + v1 + v2 + v3, incl = sum;
+  for (int m = 1; m < 64; m <<= 1) {
+    const int o = __shfl_up(incl, m);
+    if ((tid & 63) >= m) incl += o;
+  }
+  __shared__ int wsum[16];
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  int ex = base + incl - sum;
+  int *h = hist + (size_t)b * kMdsCells;
+  h[c0] = ex;
+  h[c0 + 1] = ex + v0;
+  h[c0 + 2] = ex + v0 + v1;
+  h[c0 + 3] = ex + v0 + v1 + v2;
+}
+
+// scatter: perm[sorted position] = original index (order inside a cell is irrelevant)
+__global__ __launch_bounds__(256) void mds_sort_scatter_kernel(int n, const int *__restrict__ cell_of,
+                                                               int *__restrict__ hist,
+                                                               int *__restrict__ perm, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long b = e / n;
+    const int k = (int)(e - b * n);
+    const int pos = atomicAdd(&hist[b * kMdsCells + cell_of[e]], 1);
+    perm[b * n + pos] = k;
+  }
+}
+
+template <int PPT>
+__global__ __launch_bounds__(1024) void mds_clustered_kernel(
+    int n, int m, const float *__restrict__ xyz, const int *__restrict__ perm_all,
+    const float *__restrict__ mean_mst_length, int *__restrict__ idxs) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float yz[];  // [PPT*1024][2], lane private
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float *__restrict__ p = xyz + (size_t)b * n * 3;
+  const int *__restrict__ perm = perm_all + (size_t)b * n;
+  int *__restrict__ out = idxs + (size_t)b * m;
+  const float mml = mean_mst_length[b];
+  const float t = (float)(5.0 * (double)mml * (double)mml);
+  // every point at squared distance >= cut2 contributes sn_expf(-d/t) == 0 exactly
+  const float cut2 = 104.0f * t * 1.0001f;
+
+  float px[PPT], tmp[PPT];
+  unsigned low[PPT];  // (bitrev10(k mod 1024) << 16) | (k << 1) | (k >= 8192), ~0 for padding
+  float cx = 0.f, cy = 0.f, cz = 0.f, rho = -1.f;  // lane i < PPT: bounding sphere of slot i
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    const int s = ((i * 16 + wave) << 6) + lane;  // sorted position
+    const bool valid = s < n;
+    const int k = valid ? perm[s] : 0;
+    const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+    px[i] = valid ? x : 0.f;
+    yz[2 * (i * 1024 + tid) + 0] = valid ? y : 0.f;
+    yz[2 * (i * 1024 + tid) + 1] = valid ? z : 0.f;
+    // Padding entries start at 1e9 like a picked point: 1e9f + e == 1e9f for every e <= 2, so
+    // they stay there without a validity test and never win the arg-min.
+    tmp[i] = valid ? 0.f : 1e9f;
+    low[i] = valid ? ((__brev((unsigned)(k & 1023)) >> 22) << 16) | ((unsigned)k << 1) | (k >= 8192 ? 1u : 0u)
+                   : 0xffffffffu;
+    // bounding sphere of this wave's cluster i: centre = mean, radius = max distance (+ slack)
+    float sx = valid ? x : 0.f, sy = valid ? y : 0.f, sz = valid ? z : 0.f, cnt = valid ? 1.f : 0.f;
+    for (int mm = 1; mm < 64; mm <<= 1) {
+      sx += __shfl_xor(sx, mm);
+      sy += __shfl_xor(sy, mm);
+      sz += __shfl_xor(sz, mm);
+      cnt += __shfl_xor(cnt, mm);
+    }
+    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+    const float mx = sx * inv, my = sy * inv, mz = sz * inv;
+    float r2 = valid ? ((x - mx) * (x - mx) + (y - my) * (y - my)) + (z - mz) * (z - mz) : 0.f;
+    for (int mm = 1; mm < 64; mm <<= 1) r2 = __builtin_fmaxf(r2, __shfl_xor(r2, mm));
+    if (lane == i) {
+      cx = mx;
+      cy = my;
+      cz = mz;
+      rho = cnt > 0.f ? __builtin_sqrtf(r2) * 1.0001f + 1e-7f : -1.f;  // -1: empty slot
+    }
+  }
+  // lane i < PPT: squared reach of slot i -- a pick farther than this from the slot's centre
+  // adds exactly 0 to every point of the slot (margins cover the rounding of the test itself)
+  float reach2 = -1.f;
+  if (rho >= 0.f) {
+    const float reach = (__builtin_sqrtf(cut2) + rho) * 1.001f;
+    reach2 = reach * reach;
+  }
+  int last = 0;
+  if (tid == 0) out[0] = 0;
+  // The pick's coordinates travel with the arg-min through LDS (a global read of xyz[last] at
+  // the top of each of the 16383 dependent rounds would sit on the critical path).
+  __shared__ unsigned wave_val[2][16];
+  __shared__ float4 wave_pick[2][16];  // x, y, z, low bits
+  const unsigned kBig = __float_as_uint(1e9f);
+  const float x0 = p[0], y0 = p[1], z0 = p[2];
+  float x1 = x0, y1 = y0, z1 = z0;
+  unsigned last_low = 0;  // low bits of point 0
+
+  for (int j = 1; j < m; ++j) {
+    // which slots of this wave can receive a non-zero update?
+    const float ddx = cx - x1, ddy = cy - y1, ddz = cz - z1;
+    const unsigned mask = (unsigned)__ballot((ddx * ddx + ddy * ddy) + ddz * ddz < reach2);
+    unsigned mn = 0xffffffffu;  // densities are >= 0: their bit patterns order like the floats
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      if ((mask >> i) & 1u) {  // wave-uniform
+        const float v = (low[i] == last_low) ? 1e9f : tmp[i];
+        const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
+        const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float e = sn_expf(-d / t);
+        // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
+        tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
+      }
+      mn = umin32(mn, __float_as_uint(tmp[i]));
+    }
+    // Arg-min of (density, bitrev, k) inside the wave.  Common case: the minimum density is
+    // held by exactly one entry, found with one compare per slot; exact ties take the full
+    // key comparison.
+    const unsigned wm = wave_min_u32(mn);
+    int hits = 0, istar = 0;  // scalar: number of entries equal to wm, and their slot
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      const int c = __popcll(__ballot(__float_as_uint(tmp[i]) == wm));
+      hits += c;
+      istar += i * c;
+    }
+    unsigned wl = 0xffffffffu;
+    float wx = 0.f;
+    int wi = 0;
+    bool winner;
+    if (hits == 1) {
+      winner = mn == wm;
+      wi = istar;
+#pragma unroll
+      for (int i = 0; i < PPT; ++i)
+        if (i == istar) {  // wave-uniform pick of a statically indexed register
+          asm volatile("");
+          wl = low[i];
+          wx = px[i];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const bool lt = __float_as_uint(tmp[i]) == wm && low[i] < wl;
+        wl = lt ? low[i] : wl;
+        wx = lt ? px[i] : wx;
+        wi = lt ? i : wi;
+      }
+      const unsigned wlmin = wave_min_u32(wl);
+      winner = wl == wlmin && wl != 0xffffffffu;  // lows of real points are unique
+    }
+    const int buf = j & 1;
+    if (lane == 0) wave_val[buf][wave] = wm;
+    if (winner) {
+      const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
+      wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
+    }
+    __syncthreads();
+    // every wave reduces the 16 hand-offs in its own registers
+    const int l16 = lane & 15;
+    const unsigned v16 = wave_val[buf][l16];
+    const float4 pk = wave_pick[buf][l16];
+    const unsigned minv = row_min_u32(v16);
+    const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
+    const unsigned minl = row_min_u32(lw);
+    const int wsel = (int)__builtin_ctzll(__ballot(lw == minl));
+    if (__builtin_amdgcn_readfirstlane((int)minv) >= (int)kBig) {
+      last = 0;  // nothing below 1e9: the reference's threads all report (1e9, index 0)
+      last_low = 0;
+      x1 = x0;
+      y1 = y0;
+      z1 = z0;
+    } else {
+      last_low = (unsigned)__builtin_amdgcn_readlane((int)lw, wsel);
+      last = (int)((last_low >> 1) & 0x7fffu);
+      x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.x), wsel));
+      y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.y), wsel));
+      z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.z), wsel));
+    }
+    if (tid == 0) out[j] = last;
+  }
+}
+
 // generic fallback for clouds that do not fit the register budget: state in global memory
 __global__ __launch_bounds__(1024) void mds_kernel_generic(int n, int m,
                                                            const float *__restrict__ xyz,
@@ -223,15 +512,22 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(int c, int n, int m,
   }
 }
 
-int lin_blocks(long total) {
+static int lin_blocks(long total) {
   const long b = (total + 255) / 256;
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 }  // namespace
 
+// dynamic y/z slots (8 B x 1024 lanes x slots) + 768 B of static hand-off storage <= 160 KiB
+static bool mds_use_clustered(int n) {
+  return n >= 2048 && (size_t)((n + 1023) / 1024) * 8192 + 1024 <= 160 * 1024;
+}
+
 extern "C" size_t sn_mds_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
+  if (mds_use_clustered(n))  // perm + cell ids + cell offsets + bounding boxes
+    return sn::align_up((size_t)b * n * 4, 256) * 2 + (size_t)b * kMdsCells * 4 + 256 * (size_t)b;
   int bs = 1;
   while (bs * 2 <= n && bs < 1024) bs *= 2;
   return (n + bs - 1) / bs <= 24 ? 0 : (size_t)b * n * 4;
@@ -251,6 +547,42 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
   const int ppt = (n + bs - 1) / bs;
   hipStream_t s = sn::as_stream(stream);
   if (sn::prof_enabled()) sn::prof_begin("mds", s);
+  if (mds_use_clustered(n)) {
+    SN_REQUIRE(workspace && workspace_bytes >= sn_mds_workspace_bytes(b, n),
+               "sn_mds: workspace too small (%zu < %zu)", workspace_bytes, sn_mds_workspace_bytes(b, n));
+    char *w = static_cast<char *>(workspace);
+    int *perm = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
+    int *cell_of = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
+    int *hist = reinterpret_cast<int *>(w); w += (size_t)b * kMdsCells * 4;
+    float *bbox = reinterpret_cast<float *>(w);
+    mds_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz, bbox, hist, cell_of);
+    const long total = (long)b * n;
+    mds_sort_scatter_kernel<<<lin_blocks(total), 256, 0, s>>>(n, cell_of, hist, perm, total);
+    const size_t lds = (size_t)ppt * 1024 * 8;
+#define SN_MDSC(P)                                                                               \
+  {                                                                                              \
+    static bool once = [] {                                                                      \
+      return hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_clustered_kernel<P>),       \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == \
+             hipSuccess;                                                                         \
+    }();                                                                                         \
+    (void)once;                                                                                  \
+    mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, mean_mst_length, idx);          \
+  }
+    // exact slot counts near the register limit (19 at SpareNet's n = 19384): every unused
+    // slot costs three VGPRs and the 1024-lane workgroup only has 128 per lane
+    if (ppt <= 2) SN_MDSC(2)
+    else if (ppt <= 4) SN_MDSC(4)
+    else if (ppt <= 8) SN_MDSC(8)
+    else if (ppt <= 12) SN_MDSC(12)
+    else if (ppt <= 16) SN_MDSC(16)
+    else if (ppt == 17) SN_MDSC(17)
+    else if (ppt == 18) SN_MDSC(18)
+    else SN_MDSC(19)
+#undef SN_MDSC
+    if (sn::prof_enabled()) sn::prof_end("mds", s);
+    return sn::launch_status("sn_mds");
+  }
 #define SN_MDS(P) mds_kernel<P, 0, 1024><<<b, 1024, 0, s>>>(n, m, xyz, mean_mst_length, idx, lg)
 #define SN_MDS_Z(P, C) \
   mds_kernel<P, C, 1024><<<b, 1024, (size_t)n * 4 * C, s>>>(n, m, xyz, mean_mst_length, idx, lg)
