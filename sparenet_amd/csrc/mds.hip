@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void mds_kernel(int n, int m, const float *__
 // of a wave mixes points from all over the cloud, so nothing can be skipped in SIMD.  Here
 // the points are first put in Morton order; slot i of wave w holds the 64 spatially adjacent
 // points of cluster i*16+w.  Every round one lane per slot tests the cluster's bounding
-// sphere against the ball (one ballot), and only the 1-3 slots that can receive a non-zero
+// box against the ball (one ballot), and only the 1-3 slots that can receive a non-zero
 // update are evaluated; the others keep their densities untouched -- bit-identical results,
 // ~4x fewer issued ops per round.  The arg-min is order independent: every candidate carries
 // the key (density bits, bitrev(k mod 1024), k) of its ORIGINAL index k.
@@ -271,10 +271,48 @@ __global__ __launch_bounds__(256) void mds_sort_scatter_kernel(int n, const int 
   }
 }
 
+// sn_expf (include/sn_expf.h) for arguments x <= 0 (or NaN): the same correctly rounded
+// operations in the same order, so it returns the bits sn_expf returns.  The x > 88 clamp is
+// unreachable here; the final scaling is one v_ldexp_f32, which rounds y * 2^n once -- exactly
+// what the header's two-step multiply does for results in the subnormals.
+__device__ __forceinline__ float sn_expf_nonpositive(float x) {
+  const float magic = 12582912.0f;
+  const float t = __builtin_fmaf(x, 1.44269504088896341f, magic);
+  const float fn = t - magic;
+  const int n = (int)fn;
+  float r = __builtin_fmaf(fn, -0.693359375f, x);
+  r = __builtin_fmaf(fn, 2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+  p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+  p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+  p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+  p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+  const float r2 = r * r;
+  const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+  return x > -104.0f ? __builtin_ldexpf(y, n) : 0.0f;
+}
+
+// -d / t.  With rt = RN(1/t), the product refined twice through the exact residual is the
+// correctly rounded quotient (Markstein's theorem; tools/probe/div_probe.hip checks it
+// exhaustively for 64 divisors x 5.8e8 dividends on the device).  The caller only takes this
+// path when no intermediate can overflow and t is far from the subnormals; quotients that
+// underflow have |x| < 2^-26, where sn_expf(x) == 1 whatever the last bits of x are.
+__device__ __forceinline__ float neg_div(float d, float t, float rt, bool fast) {
+  if (!fast) return -d / t;
+  const float n = -d;
+  float q = n * rt;
+  float r = __builtin_fmaf(-t, q, n);
+  q = __builtin_fmaf(r, rt, q);
+  r = __builtin_fmaf(-t, q, n);
+  return __builtin_fmaf(r, rt, q);
+}
+
 template <int PPT>
 __global__ __launch_bounds__(1024) void mds_clustered_kernel(
     int n, int m, const float *__restrict__ xyz, const int *__restrict__ perm_all,
-    const float *__restrict__ mean_mst_length, int *__restrict__ idxs) {
+    const float *__restrict__ bbox, const float *__restrict__ mean_mst_length,
+    int *__restrict__ idxs) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float yz[];  // [PPT*1024][2], lane private
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -285,10 +323,19 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
   const float t = (float)(5.0 * (double)mml * (double)mml);
   // every point at squared distance >= cut2 contributes sn_expf(-d/t) == 0 exactly
   const float cut2 = 104.0f * t * 1.0001f;
+  const float rt = 1.0f / t;
+  float diag2 = 0.f;  // the squared diagonal of the cloud's bounding box bounds every d
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ext = bbox[b * 6 + 3 + a] - bbox[b * 6 + a];
+    diag2 += ext * ext;
+  }
+  const bool fast_div = t >= 0x1p-40f && t <= 0x1p40f && diag2 * rt < 0x1p100f;
 
   float px[PPT], tmp[PPT];
   unsigned low[PPT];  // (bitrev10(k mod 1024) << 16) | (k << 1) | (k >= 8192), ~0 for padding
-  float cx = 0.f, cy = 0.f, cz = 0.f, rho = -1.f;  // lane i < PPT: bounding sphere of slot i
+  // lane i < PPT: axis-aligned bounding box of slot i
+  float blx = 3e38f, bly = 3e38f, blz = 3e38f, bhx = -3e38f, bhy = -3e38f, bhz = -3e38f;
 #pragma unroll
   for (int i = 0; i < PPT; ++i) {
     const int s = ((i * 16 + wave) << 6) + lane;  // sorted position
@@ -303,32 +350,25 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
     tmp[i] = valid ? 0.f : 1e9f;
     low[i] = valid ? ((__brev((unsigned)(k & 1023)) >> 22) << 16) | ((unsigned)k << 1) | (k >= 8192 ? 1u : 0u)
                    : 0xffffffffu;
-    // bounding sphere of this wave's cluster i: centre = mean, radius = max distance (+ slack)
-    float sx = valid ? x : 0.f, sy = valid ? y : 0.f, sz = valid ? z : 0.f, cnt = valid ? 1.f : 0.f;
+    // bounding box of this wave's cluster i (kept by lane i)
+    float lx = valid ? x : 3e38f, ly = valid ? y : 3e38f, lz = valid ? z : 3e38f;
+    float hx = valid ? x : -3e38f, hy = valid ? y : -3e38f, hz = valid ? z : -3e38f;
     for (int mm = 1; mm < 64; mm <<= 1) {
-      sx += __shfl_xor(sx, mm);
-      sy += __shfl_xor(sy, mm);
-      sz += __shfl_xor(sz, mm);
-      cnt += __shfl_xor(cnt, mm);
+      lx = __builtin_fminf(lx, __shfl_xor(lx, mm));
+      ly = __builtin_fminf(ly, __shfl_xor(ly, mm));
+      lz = __builtin_fminf(lz, __shfl_xor(lz, mm));
+      hx = __builtin_fmaxf(hx, __shfl_xor(hx, mm));
+      hy = __builtin_fmaxf(hy, __shfl_xor(hy, mm));
+      hz = __builtin_fmaxf(hz, __shfl_xor(hz, mm));
     }
-    const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
-    const float mx = sx * inv, my = sy * inv, mz = sz * inv;
-    float r2 = valid ? ((x - mx) * (x - mx) + (y - my) * (y - my)) + (z - mz) * (z - mz) : 0.f;
-    for (int mm = 1; mm < 64; mm <<= 1) r2 = __builtin_fmaxf(r2, __shfl_xor(r2, mm));
-    if (lane == i) {
-      cx = mx;
-      cy = my;
-      cz = mz;
-      rho = cnt > 0.f ? __builtin_sqrtf(r2) * 1.0001f + 1e-7f : -1.f;  // -1: empty slot
+    if (lane == i) {  // an empty cluster keeps lo = 3e38: infinitely far from every pick
+      blx = lx, bly = ly, blz = lz;
+      bhx = hx, bhy = hy, bhz = hz;
     }
   }
-  // lane i < PPT: squared reach of slot i -- a pick farther than this from the slot's centre
-  // adds exactly 0 to every point of the slot (margins cover the rounding of the test itself)
-  float reach2 = -1.f;
-  if (rho >= 0.f) {
-    const float reach = (__builtin_sqrtf(cut2) + rho) * 1.001f;
-    reach2 = reach * reach;
-  }
+  // a pick whose squared distance to the box reaches this adds exactly 0 to every point of the
+  // slot (the margin covers the rounding of the test and of the d computed in the update)
+  const float far2 = cut2 * 1.001f;
   int last = 0;
   if (tid == 0) out[0] = 0;
   // The pick's coordinates travel with the arg-min through LDS (a global read of xyz[last] at
@@ -342,8 +382,10 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
 
   for (int j = 1; j < m; ++j) {
     // which slots of this wave can receive a non-zero update?
-    const float ddx = cx - x1, ddy = cy - y1, ddz = cz - z1;
-    const unsigned mask = (unsigned)__ballot((ddx * ddx + ddy * ddy) + ddz * ddz < reach2);
+    const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
+    const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
+    const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
+    const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
     unsigned mn = 0xffffffffu;  // densities are >= 0: their bit patterns order like the floats
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
@@ -352,7 +394,7 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
         const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
         const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
         const float d = (dx * dx + dy * dy) + dz * dz;
-        const float e = sn_expf(-d / t);
+        const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
         // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
         tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
       }
@@ -567,7 +609,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
              hipSuccess;                                                                         \
     }();                                                                                         \
     (void)once;                                                                                  \
-    mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, mean_mst_length, idx);          \
+    mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, bbox, mean_mst_length, idx);          \
   }
     // exact slot counts near the register limit (19 at SpareNet's n = 19384): every unused
     // slot costs three VGPRs and the 1024-lane workgroup only has 128 per lane

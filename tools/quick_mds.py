@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])  # A/B a saved build
 from sparenet_amd.cuda.MDS.MDS_module import minimum_density_sample
 from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
 
@@ -15,7 +17,11 @@ def timeit(fn, K=3, warm=1):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / K
 x = torch.rand(32, 19384, 3, device=dev); mml = torch.full((32,), 0.0085, device=dev)
-print(f"mds B=32 n=19384 m=16384: {timeit(lambda: minimum_density_sample(x, 16384, mml), K=2):.2f} ms")
+print(f"mds B=32 n=19384 m=16384: {timeit(lambda: minimum_density_sample(x, 16384, mml), K=3):.2f} ms")
+for mm in (0.03, 0.1):
+    mml2 = torch.full((32,), mm, device=dev)
+    print(f"mds mml={mm}: {timeit(lambda: minimum_density_sample(x, 16384, mml2), K=2):.2f} ms")
+if os.environ.get("MDS_ONLY"): sys.exit(0)
 data = torch.rand(32, 16384, 3, device=dev) - 0.5
 cdm = ComputeDepthMaps("orthorgonal", 1.0, 256).to(dev)
 for radii in ([5.0, 7.0, 10.0], [0.02, 0.05], [10.0]):
