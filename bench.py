@@ -53,6 +53,8 @@ def parse():
                          "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-other-ops", action="store_true",
+                    help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
     return ap.parse_args()
 
 
@@ -84,6 +86,7 @@ class HotPath:
         self.radius_list = radius_list
         self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ev = {}
+        self.last_mean_mst = None
 
     def _emd(self, pred, gt):
         """emdFunction with the effective-pair counter attached."""
@@ -128,6 +131,7 @@ class HotPath:
         pen, _, mml = self.expansion(p3, PRIM, ALPHA)
         loss_exp = pen.mean()
         loss_exp.backward()
+        self.last_mean_mst = mml.detach()
         mark("expansion")
         p4 = (pred.detach() - 0.5).requires_grad_(True)
         acc = None
@@ -185,6 +189,53 @@ def cpu_baseline():
         "chamfer_pairs_per_sec": pairs_cd / t_cd,
         "emd_pairs_per_sec": pairs_emd / t_emd,
     }
+
+
+def other_ops(dev, pred, mean_mst):
+    """SURVEY 8(a) rows that are not part of the loss step (they run inside the generator's
+    forward): timed once each, outside the headline region, for the record."""
+    from sparenet_amd.cuda.MDS.MDS_module import minimum_density_sample, gather_operation
+    from sparenet_amd.cuda.gridding import Gridding, GriddingReverse
+    from sparenet_amd.cuda.cubic_feature_sampling import CubicFeatureSampling
+
+    def ms(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    g = torch.Generator(device="cpu").manual_seed(99)
+    extra = torch.rand(B, 3000, 3, generator=g).to(dev)
+    cloud = torch.cat([pred.detach(), extra], dim=1).contiguous()          # [32,19384,3]
+    out = {}
+    idx = minimum_density_sample(cloud, N, mean_mst)
+    out["mds_19384_to_16384"] = ms(lambda: minimum_density_sample(cloud, N, mean_mst))
+    feat = torch.cat([cloud, cloud[:, :, :1]], dim=2).transpose(1, 2).contiguous()   # [32,4,19384]
+    out["gather_c4"] = ms(lambda: gather_operation(feat, idx))
+    pts = ((pred.detach() - 0.5) * 1.9).requires_grad_(True)              # inside (-1,1)
+    grid_op, rev_op, cubic = Gridding(64), GriddingReverse(64), CubicFeatureSampling()
+
+    def gridding_fb():
+        grid = grid_op(pts)
+        grid.sum().backward()
+    out["gridding64_fwd_bwd"] = ms(gridding_fb)
+    vol = torch.rand(B, 64, 64, 64, generator=g).to(dev).requires_grad_(True)
+
+    def reverse_fb():
+        rev_op(vol).sum().backward()
+    out["gridding_reverse64_fwd_bwd"] = ms(reverse_fb)
+    feats = torch.rand(B, 32, 32, 32, 32, generator=g).to(dev).requires_grad_(True)
+    q = (pred.detach()[:, :2048] * 30.0 + 0.5).contiguous()
+
+    def cubic_fb():
+        cubic(q, feats).sum().backward()
+    out["cubic_sampling_2048x32c_fwd_bwd"] = ms(cubic_fb)
+    return out
 
 
 def main():
@@ -310,6 +361,8 @@ def main():
             "losses": [float(x) for x in losses.tolist()],
             "roofline": roofline,
         }
+        if world == 1 and not args.no_other_ops:
+            out["other_ops_ms_rank0"] = other_ops(dev, pred, hp.last_mean_mst)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
