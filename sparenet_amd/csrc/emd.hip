@@ -19,23 +19,31 @@
 //   * 4 launches per iteration instead of 7: the unassigned list for the next iteration is
 //     produced by Assign itself (losers and evicted points append with a wave-aggregated
 //     atomic) -- no count / scan / compaction kernels.
-//   * Bid is the hot kernel (fp32 VALU bound).  Every lane of a wave is a different bidder
-//     and the wave walks a wave-UNIFORM target stream that arrives through the scalar cache
-//     in SGPRs (one s_load_dwordx16 = 4 targets) -- no LDS, no barrier in the scan.
-//   * fp32 packed filter + exact path: a target is evaluated exactly (correctly rounded
-//     sqrt, fp64 detour, top-2 update) only if a conservative fp32 test says it could enter
-//     the bidder's top-2; thresholds are seeded from the bidder's previous two favourites.
-//     ~2-4 % of the wave-steps take the exact path; results stay bit-identical.
+//   * Bid is the hot kernel.  The pairwise search is a filtered one: a [targets x 4].[4 x bidders]
+//     fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32) gives |t|^2 - 2 t.x for 256 pairs per
+//     instruction and a per-lane threshold decides which pairs can still enter a bidder's
+//     top-2; the rare survivors are queued in LDS and evaluated 64 at a time with the
+//     reference's exact arithmetic (correctly rounded sqrt, fp64 detour).  Thresholds are seeded
+//     from the bidder's previous two favourites (first iteration: two near targets found
+//     through a Morton sort of the targets).  Results stay bit-identical.
 //   * the unassigned count is only known on the device, so a fixed XCD-aware grid adapts:
 //     S = 2^k <= 64 waves share one group of 64 bidders, each scanning n/S targets; up to
 //     16 of them merge in LDS, the rest through emd_bid_finish_kernel.
 //   * GetMax: deterministic atomicMax of the bidder index inside the window.
+#include "cloud_sort.hpp"
 #include "common.hpp"
 
 namespace {
 
+// split constants (tools build A/B variants with -D)
+#ifndef SN_EMD_MAXSEG
+#define SN_EMD_MAXSEG 64
+#endif
+#ifndef SN_EMD_G
+#define SN_EMD_G 32
+#endif
 constexpr int kThreads = 256;     // element-wise kernels
-constexpr int kBlocksPerCloud = 32;  // bid kernel: 32 workgroups x 16 waves = 512 waves per cloud (swept 8..64)
+constexpr int kBlocksPerCloud = SN_EMD_G;  // bid kernel: 32 workgroups x 16 waves = 512 waves per cloud (swept 8..64)
 
 struct Top2 {
   float best, better;
@@ -49,16 +57,6 @@ __device__ __forceinline__ float bid_value(float tx, float ty, float tz, float p
   const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
   const float s = (xx + yy) + zz;
   return (float)((3.0 - (double)__builtin_sqrtf(s)) - (double)p);
-}
-
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// FILTER-ONLY squared distance of two targets at once: fused multiply-adds (6 packed ops
-// instead of 8).  It differs from the exact (dx*dx + dy*dy) + dz*dz by <= 2 ulp, which the
-// filter margins absorb; every target that passes is re-evaluated exactly by sq_dist.
-__device__ __forceinline__ f2 sq_dist2_fast(f2 tx, f2 ty, f2 tz, float x1, float y1, float z1) {
-  const f2 dx = tx - x1, dy = ty - y1, dz = tz - z1;
-  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, dx * dx));
 }
 
 __device__ __forceinline__ float sq_dist(float tx, float ty, float tz, float x1, float y1,
@@ -155,14 +153,18 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
     atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
 }
 
-// Prepared target stream: one 32-byte record per PAIR of targets,
-//   [x0 x1 | y0 y1 | z0 z1 | A'0 A'1],  A'_k = filter_target(price_k),
-// so that a wave-uniform s_load_dwordx16 delivers 4 targets straight into SGPR pairs that
-// the packed fp32 ops consume as operands.  Written by emd_init_kernel, A' refreshed by
-// emd_assign_kernel for the targets whose price changed.
-__device__ __forceinline__ size_t tgt_slot(int k, int field) {
-  return (size_t)(k >> 1) * 8 + field * 2 + (k & 1);
-}
+// Two prepared target streams per cloud.
+//  * tgt4[k] = {x, y, z, A'_k}, A'_k = filter_target(price_k): what the exact path and the
+//    precise filter read (one 16-byte load).  Written by emd_init_kernel, .w refreshed by
+//    emd_assign_kernel for the targets whose price changed.
+//  * mstream: the MFMA A-operand of the coarse filter, price independent (written once).
+//    u_kj = |t_k|^2 - 2 t_k . x_j is a [targets x 4] . [4 x bidders] product with rows
+//    (-2x, -2y, -2z, |t|^2) and columns (x, y, z, 1).  v_mfma_f32_16x16x4_f32 takes ONE float
+//    per lane for A: lane l supplies A[i = l & 15][k = l >> 4].  A superblock of 64 targets is
+//    4 such operands; lane l's four values sit in one float4:
+//      mstream[(superblock * 64 + l)].q = component (l >> 4) of target 64 sb + 16 q + (l & 15)
+//    so a wave fetches 64 targets with one coalesced global_load_dwordx4 per lane.
+typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct EmdWs {
   int *assignment_inv;
@@ -173,12 +175,18 @@ struct EmdWs {
   int *max_idx;
   int *list[2];
   int *cnt[2];
-  float *tgt;  // [B, n/2, 8] prepared target stream (see tgt_slot)
+  f4 *tgt4;      // [B, n]
+  f4 *mstream;   // [B, n/64, 64], targets in Morton order (position p holds target tperm[p])
+  int *tperm;    // [B, n] sorted position -> target index
+  int *cell_of;  // [B, n] sort scratch
+  int *hist;     // [B, 4096] cell offsets of the sorted targets
+  float *bbox;   // [B, 6] bounding box of the targets (also bounds |t|^2 for the filter slack)
   float *partial;  // [B][16][4][64] float4
 };
 
 __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
                                 int *__restrict__ assignment, EmdWs ws) {
+#pragma clang fp contract(off)
   const long total = (long)B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
@@ -190,19 +198,75 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.bid[e] = -1;   // no previous favourites yet (filter seeding)
     ws.bid2[e] = -1;
     ws.list[0][e] = (int)(e % n);
-    {
+    ws.tgt4[e] = f4{xyz2[e * 3 + 0], xyz2[e * 3 + 1], xyz2[e * 3 + 2], filter_target(0.f)};
+    {  // stream position p of this cloud holds target tperm[p]
       const long bb = e / n;
-      const int k = (int)(e - bb * n);
-      float *t = ws.tgt + bb * n * 4;
-      t[tgt_slot(k, 0)] = xyz2[e * 3 + 0];
-      t[tgt_slot(k, 1)] = xyz2[e * 3 + 1];
-      t[tgt_slot(k, 2)] = xyz2[e * 3 + 2];
-      t[tgt_slot(k, 3)] = filter_target(0.f);
+      const int p = (int)(e - bb * n);
+      const float *t = xyz2 + (bb * n + ws.tperm[e]) * 3;
+      const float x = t[0], y = t[1], z = t[2];
+      const float tt = (x * x + y * y) + z * z;
+      float *m = reinterpret_cast<float *>(ws.mstream + (bb * (n >> 6) + (p >> 6)) * 64);
+      const int q = (p >> 4) & 3, c = p & 15;
+      m[(0 * 16 + c) * 4 + q] = -2.f * x;
+      m[(1 * 16 + c) * 4 + q] = -2.f * y;
+      m[(2 * 16 + c) * 4 + q] = -2.f * z;
+      m[(3 * 16 + c) * 4 + q] = tt;
     }
     if (e < B) {
       ws.cnt[0][e] = n;
       ws.cnt[1][e] = 0;
     }
+  }
+}
+
+// First-iteration seeds.  The bid filter needs, per bidder, two real targets whose values
+// bound the final `better` from below; later iterations use the previous favourites, the first
+// one has none and would evaluate ~75 targets per bidder exactly before its thresholds
+// tighten.  Targets are already in Morton order: a window of 16 sorted positions around the
+// bidder's own cell supplies candidates, the two nearest become bid/bid2.  ANY two distinct
+// targets are valid seeds; better ones only make the filter reject more.
+__global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
+                                                            const float *__restrict__ xyz1,
+                                                            const float *__restrict__ xyz2,
+                                                            EmdWs ws) {
+#pragma clang fp contract(off)
+  const long total = (long)B * n;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long bb = e / n;
+    const float x = xyz1[e * 3 + 0], y = xyz1[e * 3 + 1], z = xyz1[e * 3 + 2];
+    const float *box = ws.bbox + bb * 6;
+    unsigned q[3];
+    const float v[3] = {x, y, z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float ext = box[3 + a] - box[a];
+      const float f = ext > 0.f ? (v[a] - box[a]) * (15.999f / ext) : 0.f;
+      q[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
+    }
+    const int c = (int)morton3_4bit(q[0], q[1], q[2]);
+    const int start = c > 0 ? ws.hist[bb * kSortCells + c - 1] : 0;  // END of the previous cell
+    int lo = start - 4;
+    lo = lo < 0 ? 0 : (lo > n - 16 ? n - 16 : lo);
+    float s1 = 3e38f, s2 = 3e38f;
+    int k1 = -1, k2 = -1;
+    for (int p = lo; p < lo + 16; ++p) {
+      const int k = ws.tperm[bb * n + p];
+      const float *t = xyz2 + (bb * n + k) * 3;
+      const float dx = t[0] - x, dy = t[1] - y, dz = t[2] - z;
+      const float sq = (dx * dx + dy * dy) + dz * dz;
+      if (sq < s1) {
+        s2 = s1;
+        k2 = k1;
+        s1 = sq;
+        k1 = k;
+      } else if (sq < s2) {
+        s2 = sq;
+        k2 = k;
+      }
+    }
+    ws.bid[e] = k1;
+    ws.bid2[e] = k2;
   }
 }
 
@@ -215,7 +279,7 @@ struct BidOut {
 
 constexpr int kBidWaves = 16;
 constexpr int kBidThreads = kBidWaves * 64;
-constexpr int kMaxSegments = 64;                          // waves per bidder group, at most
+constexpr int kMaxSegments = SN_EMD_MAXSEG;                          // waves per bidder group, at most
 constexpr int kMaxSplit = kMaxSegments / kBidWaves;       // workgroups per bidder group, at most
 constexpr int kMaxSplitGroups = 16;                       // groups per cloud that may be split
 
@@ -225,9 +289,10 @@ constexpr int kMaxSplitGroups = 16;                       // groups per cloud th
 struct BidSplit {
   int s_total, s_block, nb;
 };
-__host__ __device__ inline BidSplit bid_split(int ngroups, int G) {
+__host__ __device__ inline BidSplit bid_split(int ngroups, int G, int n) {
   int s = 1;
-  while (s < kMaxSegments && s * 2 * ngroups <= G * kBidWaves) s *= 2;
+  // a segment is a whole number of 64-target superblocks (n is a multiple of 1024)
+  while (s < kMaxSegments && s * 2 * ngroups <= G * kBidWaves && (n / (s * 2)) % 64 == 0) s *= 2;
   if (s > kBidWaves && ngroups > kMaxSplitGroups) s = kBidWaves;
   BidSplit r;
   r.s_total = s;
@@ -247,41 +312,76 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const
 }
 
 // ---------------------------------------------------------------------------------------
-// Bid kernel.  Every lane of a wave is a DIFFERENT bidder and the whole wave walks the SAME
-// targets, so targets are wave-uniform and travel through the scalar cache into SGPRs
-// (measured: feeding them through LDS as broadcast ds_read_b128 is LDS-issue bound at
-// ~45 cycles per target step; the packed-math filter itself needs ~26).
-// A workgroup has 16 waves.  S = 2^k <= 16 waves share one group of 64 bidders, wave s
-// scanning targets [s n/S, (s+1) n/S); the S partial top-2's meet in LDS.  S is chosen on
-// the device from the unassigned count so that the fixed grid stays busy when few bidders
-// are left (tail iterations), and is 1 while there are >= 64 * waves bidders.
+// Bid kernel: a two-level filter in front of the exact evaluation.
+//
+// level 1 (matrix cores).  A wave serves 64 bidders and walks its target segment in
+//   superblocks of 64 targets.  For bidder group g (16 bidders) and target block q (16 targets)
+//   one v_mfma_f32_16x16x4_f32 returns u = |t|^2 - 2 t.x for the 256 pairs; lane l receives
+//   the four targets 16 q + 4 (l >> 4) + r of bidder 16 g + (l & 15).  A pair can only matter
+//   if u <= T'_j, T'_j = Rmax |Rmax| (1 + 2^-20) - |x_j|^2 + slack, Rmax = A'max - c'_j: the
+//   per-target A'_k of the precise filter is replaced by its upper bound over all targets
+//   (prices never fall below `price_floor`), which makes the threshold a per-LANE constant.
+//   Cost: 16 MFMA (32 cycles each, exact fp32 = an fmaf chain) + ~44 VALU per 4096 pairs.
+//   The slack 2^-18 (max|t|^2 + |x|^2) covers the fmaf chain's rounding (4 roundings of
+//   partial sums <= 2 (|t|^2 + |x|^2)), the rounding of the stored |t|^2 and of |x|^2, and
+//   the fp32 evaluation of T' itself.
+// hit queue.  Level-1 hits are rare and scattered over the lanes, so they are not evaluated
+//   in place: (target, bidder) pairs are appended to a per-wave LDS queue and handled 64 at a
+//   time with every lane busy.
+// level 2 (precise filter) + exact path, per queued pair.  tgt4[k] is loaded and the
+//   exact-arithmetic test s <= R' |R'|, R' = A'_k - c'_j (derivation above) applied; the
+//   survivors get the reference's arithmetic (correctly rounded sqrt, fp64 detour) and are
+//   pushed into the bidder's top-2, which lives in LDS; lanes holding pairs of the same bidder
+//   take turns (an election through LDS per round).
+//   d_k >= c  =>  level 2 passes  =>  level 1 passes, and a stale (smaller) c only lets more
+//   through, so the top-2 VALUES are those of the full scan; exact ties resolve through
+//   tie_key, which does not depend on the visiting order either.
+//
+// Work split as before: S = 2^k <= 64 waves share a group of 64 bidders, each scanning
+// n / S targets (a whole number of superblocks); up to 16 of them meet in LDS, the rest in
+// emd_bid_finish_kernel.
 // ---------------------------------------------------------------------------------------
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(4))) const float cfloat;
-typedef __attribute__((address_space(4))) const f4 cf4;
-
-// constant address space (4): nothing in the bid kernel writes the target stream or the
-// prices, and a uniform load from AS4 is always selected as a scalar (SMEM) load; the 64-bit
-// base goes through readfirstlane so that it provably lives in SGPRs.
-__device__ __forceinline__ const cfloat *uniform_ptr(const float *q) {
-  const unsigned long long a = (unsigned long long)q;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-  return (const cfloat *)(((unsigned long long)hi << 32) | lo);
+__device__ __forceinline__ float min16(const f4 a, const f4 b, const f4 c, const f4 d) {
+  const float m0 = __builtin_fminf(__builtin_fminf(a.x, a.y), a.z);
+  const float m1 = __builtin_fminf(__builtin_fminf(a.w, b.x), b.y);
+  const float m2 = __builtin_fminf(__builtin_fminf(b.z, b.w), c.x);
+  const float m3 = __builtin_fminf(__builtin_fminf(c.y, c.z), c.w);
+  const float m4 = __builtin_fminf(__builtin_fminf(d.x, d.y), d.z);
+  const float m5 = __builtin_fminf(__builtin_fminf(m0, m1), d.w);
+  return __builtin_fminf(__builtin_fminf(m2, m3), __builtin_fminf(m4, m5));
 }
 
-// 8 waves/SIMD (<= 64 VGPRs): every wave has at most two scalar loads in flight, so the
-// scalar-cache latency is hidden by wave-level parallelism
+__device__ __forceinline__ unsigned hits4(const f4 d, float thr, int shift) {
+  return ((d.x <= thr ? 1u : 0u) | (d.y <= thr ? 2u : 0u) | (d.z <= thr ? 4u : 0u) |
+          (d.w <= thr ? 8u : 0u)) << shift;
+}
+
+constexpr int kQueue = 128;  // a round appends <= 64 pairs to < 64 left-overs
+
+struct WaveTab {  // per-wave LDS: the 64 bidders it serves, and its hit queue
+  float x[64], y[64], z[64];
+  float cm[64];  // proven lower bound of the bidder's final `better` (3e38: no bidder)
+  float best[64], better[64];
+  int bi[64], bi2[64];
+  unsigned queue[kQueue];  // stream position | bidder << 20
+  int owner[64];
+};
+
+// level-1 threshold T' of one bidder: base = slack - |x|^2 is fixed, cm grows
+__device__ __forceinline__ float coarse_threshold(float cm, float base, float a_max) {
+  const float r = a_max - filter_thr(cm);
+  return __builtin_fmaf(r * __builtin_fabsf(r), 1.00000095367431640625f, base);
+}
+
 __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
-    int B, int G, int n, float eps, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    const float *__restrict__ price, const float *__restrict__ tgt,
-    const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
-    long long *__restrict__ stats) {
-  __shared__ float m_best[kBidWaves][64], m_better[kBidWaves][64];
-  __shared__ int m_bi[kBidWaves][64], m_bi2[kBidWaves][64];
+    int B, int G, int n, float eps, float price_floor, const float *__restrict__ xyz1,
+    const float *__restrict__ price, const f4 *__restrict__ tgt4, const f4 *__restrict__ mstream,
+    const float *__restrict__ bbox, const int *__restrict__ tperm, const int *__restrict__ list,
+    const int *__restrict__ cnt, BidOut A, long long *__restrict__ stats) {
+  __shared__ WaveTab tabs[kBidWaves];
   // XCD-aware decode of the 1-D grid: workgroup `lin` runs on XCD lin % 8 and every cloud's
-  // workgroups share that residue, so a cloud's 256 KB target stream + prices stay in ONE
-  // 4 MB L2 (4 clouds per XCD at B = 32) instead of all 8 MB cycling through every L2.
+  // workgroups share that residue, so a cloud's streams + prices stay in ONE 4 MB L2
+  // (4 clouds per XCD at B = 32) instead of cycling through every L2.
   const int lin = blockIdx.x;
   const int xcd = lin & 7, rr = lin >> 3;
   const int b = (rr / G) * 8 + xcd;
@@ -295,25 +395,35 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
   }
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably uniform
   const int lane = threadIdx.x & 63;
+  const int row = lane >> 4, col = lane & 15;
   const size_t o = (size_t)b * n;
   const float *__restrict__ p1 = xyz1 + o * 3;
-  const float *__restrict__ p2 = xyz2 + o * 3;
   const float *__restrict__ pr = price + o;
+  const f4 *__restrict__ t4 = tgt4 + o;
   const int *__restrict__ lst = list + o;
-  const cfloat *tg = uniform_ptr(tgt + o * 4);
-  const cfloat *prc = uniform_ptr(price + o);
+  const int *__restrict__ tp = tperm + o;
+  WaveTab &T = tabs[wave];
 
   const int ngroups = (U + 63) >> 6;
-  const BidSplit sp = bid_split(ngroups, G);
+  const BidSplit sp = bid_split(ngroups, G, n);
   const int S = sp.s_block;        // segments (waves) of one group inside this workgroup
   const int gpb = kBidWaves / S;   // bidder groups per workgroup (1 when the group is split)
   const int seg = wave & (S - 1);  // this wave's segment within the workgroup
   const int gslot = wave / S;
-  const int seg_len = n / sp.s_total;  // n % 1024 == 0, s_total <= 64: a multiple of 16
+  const int seg_len = n / sp.s_total;  // a multiple of 64
 
   // reference partition, only needed to order exact ties (emd_cuda.cu:108-109,136)
   const int block_cnt = n / 1024;
   const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
+  // upper bound of every A'_k (+ 4 ulp of 3: filter_target is only monotone up to rounding)
+  const float a_max = filter_target(price_floor) + 9.5367431640625e-07f;
+  float tmax = 0.f;  // upper bound of every stored |t|^2: the far corner of the bounding box
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float lo = bbox[b * 6 + a], hi = bbox[b * 6 + 3 + a];
+    tmax += __builtin_fmaxf(lo * lo, hi * hi);
+  }
+  tmax *= 1.0001f;
 
   // work items: (group, part) with part < nb; a workgroup takes gpb consecutive groups (nb == 1)
   // or one (group, part) (nb > 1)
@@ -324,71 +434,127 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
     const int u = grp * 64 + lane;
     const bool active = grp < ngroups && u < U;
     const int j = lst[active ? u : 0];
-    const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
     Top2 top = {-1e9f, -1e9f, -1, -1};
 
-    // seed the filter with the bidder's previous two favourites under today's prices:
-    // both are real targets, so the final `better` is at least the smaller of the two.
-    float cm = -1e9f;
-    {
-      const int pa = A.bid[o + j], pb = A.bid2[o + j];
-      if (pa >= 0 && pb >= 0) {
-        const float da = bid_value(p2[pa * 3], p2[pa * 3 + 1], p2[pa * 3 + 2], pr[pa], x1, y1, z1);
-        const float db = bid_value(p2[pb * 3], p2[pb * 3 + 1], p2[pb * 3 + 2], pr[pb], x1, y1, z1);
-        cm = __builtin_fminf(da, db);
-      }
-    }
-    float cthr = filter_thr(cm);
-
     if (grp < ngroups) {  // wave-uniform
-      // software pipelined: the next 4 targets' record pair (s_load_dwordx16) is in flight
-      // while the current 4 are evaluated
-      const cf4 *rec = (const cf4 *)(tg + (size_t)(k_begin >> 1) * 8);
-      f4 n0 = rec[0], n1 = rec[1], n2 = rec[2], n3 = rec[3];
-      for (int k = k_begin; k < k_end; k += 4) {
-        const f4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;  // [x0 x1 y0 y1][z0 z1 a0 a1] x 2
-        rec += (k + 4 < k_end) ? 4 : 0;
-        n0 = rec[0];
-        n1 = rec[1];
-        n2 = rec[2];
-        n3 = rec[3];
-        const f2 s01 = sq_dist2_fast(f2{c0.x, c0.y}, f2{c0.z, c0.w}, f2{c1.x, c1.y}, x1, y1, z1);
-        const f2 s23 = sq_dist2_fast(f2{c2.x, c2.y}, f2{c2.z, c2.w}, f2{c3.x, c3.y}, x1, y1, z1);
-        const f2 r01 = f2{c1.z, c1.w} - cthr, r23 = f2{c3.z, c3.w} - cthr;
-        // s <= R |R|: a negative R (target too expensive to matter at any distance) never passes
-        const float t0 = r01.x * __builtin_fabsf(r01.x), t1 = r01.y * __builtin_fabsf(r01.y);
-        const float t2 = r23.x * __builtin_fabsf(r23.x), t3 = r23.y * __builtin_fabsf(r23.y);
-        const bool pass[4] = {s01.x <= t0, s01.y <= t1, s23.x <= t2, s23.y <= t3};
-        // one wave-uniform branch per 4 targets; the exact path is out of line.  A filter
-        // evaluated with an older (looser) threshold only passes more, never less.
-        if (__builtin_expect(__any(pass[0] | pass[1] | pass[2] | pass[3]), 0)) {
-          const int ku = __builtin_amdgcn_readfirstlane(k);
+      {
+        const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
+        // seed the filter with the bidder's previous two favourites under today's prices:
+        // both are real targets, so the final `better` is at least the smaller of the two.
+        float cm = -1e9f;
+        const int pa = A.bid[o + j], pb = A.bid2[o + j];
+        if (pa >= 0 && pb >= 0) {
+          const f4 ta = t4[pa], tb = t4[pb];
+          const float da = bid_value(ta.x, ta.y, ta.z, pr[pa], x1, y1, z1);
+          const float db = bid_value(tb.x, tb.y, tb.z, pr[pb], x1, y1, z1);
+          cm = __builtin_fminf(da, db);
+        }
+        T.x[lane] = x1;
+        T.y[lane] = y1;
+        T.z[lane] = z1;
+        T.cm[lane] = active ? cm : 3.0e38f;  // no bidder: a threshold of -inf, never a hit
+        T.best[lane] = -1e9f;
+        T.better[lane] = -1e9f;
+        T.bi[lane] = -1;
+        T.bi2[lane] = -1;
+      }
+      // the four bidders this lane filters for: bidder 16 g + col of the wave's group
+      float thr[4], base[4], bop[4];  // T', slack - |x|^2, MFMA B operand
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if (__any(pass[i])) {
-              // exact re-evaluation (separately rounded products and sums) from the stream
-              const cfloat *rr = tg + (size_t)((ku + i) >> 1) * 8 + ((ku + i) & 1);
-              const float sq = sq_dist(rr[0], rr[2], rr[4], x1, y1, z1);
-              const float d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)prc[ku + i]);
-              if (pass[i]) top2_push(top, d, ku + i, geom);
-              cm = __builtin_fmaxf(cm, top.better);
-              cthr = filter_thr(cm);
+      for (int g = 0; g < 4; ++g) {
+#pragma clang fp contract(off)
+        const int c = 16 * g + col;
+        const float x = T.x[c], y = T.y[c], z = T.z[c];
+        const float xx = (x * x + y * y) + z * z;
+        base[g] = 3.814697265625e-06f * (tmax + xx) - xx;
+        thr[g] = coarse_threshold(T.cm[c], base[g], a_max);
+        bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
+      }
+      int qcount = 0;  // wave-uniform
+
+      // 64 (or the last `count`) queued pairs, one per lane
+      auto batch = [&](int first, int count) {
+        const bool on = lane < count;
+        const unsigned e = T.queue[first + (on ? lane : 0)];
+        const int k = tp[e & 0xfffffu], c = (int)(e >> 20);  // stream position -> target
+        const f4 t = t4[k];
+        const float sq = sq_dist(t.x, t.y, t.z, T.x[c], T.y[c], T.z[c]);
+        bool pend = on && filter_pass(sq, t.w, filter_thr(T.cm[c]));  // level 2
+        float d = 0.f;
+        if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pr[k]);
+        volatile int *own = T.owner;
+        while (__any(pend)) {  // lanes holding pairs of the same bidder take turns
+          asm volatile("" ::: "memory");
+          if (pend) own[c] = lane;
+          if (pend && own[c] == lane) {
+            Top2 tp = {T.best[c], T.better[c], T.bi[c], T.bi2[c]};
+            top2_push(tp, d, k, geom);
+            T.best[c] = tp.best;
+            T.better[c] = tp.better;
+            T.bi[c] = tp.best_i;
+            T.bi2[c] = tp.better_i;
+            T.cm[c] = __builtin_fmaxf(T.cm[c], tp.better);
+            pend = false;
+          }
+        }
+        asm volatile("" ::: "memory");
+      };
+
+      const f4 *ms = mstream + ((size_t)b * (n >> 6) + (k_begin >> 6)) * 64 + lane;
+      f4 a_next = ms[0];
+      for (int kb = k_begin; kb < k_end; kb += 64) {
+        const f4 a = a_next;
+        ms += (kb + 64 < k_end) ? 64 : 0;
+        a_next = ms[0];  // the next superblock is in flight during this one
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f4 zero = {0.f, 0.f, 0.f, 0.f};
+          const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
+          const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
+          const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
+          const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+          if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
+            // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
+            unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
+                          hits4(d3, thr[g], 12);
+            bool drained = false;
+            while (__any(hm != 0)) {
+              const bool has = hm != 0;
+              const int i = has ? __builtin_ctz(hm) : 0;
+              hm &= hm - 1;
+              const unsigned long long bal = __ballot(has);
+              const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
+                                           (unsigned)(bal >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+              if (has)
+                T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
+                               ((unsigned)(16 * g + col) << 20);
+              qcount += __popcll(bal);
+              while (qcount >= 64) {
+                qcount -= 64;
+                batch(qcount, 64);
+                drained = true;
+              }
+            }
+            if (drained) {
+#pragma unroll
+              for (int gg = 0; gg < 4; ++gg)
+                thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
             }
           }
         }
       }
+      if (qcount > 0) batch(0, qcount);
+      top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
     }
     // merge the S partial results of a bidder group (segment 0's wave collects)
     if (S > 1) {
-      m_best[wave][lane] = top.best;
-      m_better[wave][lane] = top.better;
-      m_bi[wave][lane] = top.best_i;
-      m_bi2[wave][lane] = top.better_i;
       __syncthreads();
-      if (seg == 0)
+      if (seg == 0 && grp < ngroups)
         for (int w = wave + 1; w < wave + S; ++w)
-          top2_merge(top, m_best[w][lane], m_better[w][lane], m_bi[w][lane], m_bi2[w][lane], geom);
-      __syncthreads();  // LDS merge slots are reused by the next group
+          top2_merge(top, tabs[w].best[lane], tabs[w].better[lane], tabs[w].bi[lane],
+                     tabs[w].bi2[lane], geom);
+      __syncthreads();  // the tables are rewritten by the next work item
     }
     if (seg == 0 && grp < ngroups) {
       if (sp.nb == 1) {
@@ -408,7 +574,7 @@ __global__ __launch_bounds__(kBidThreads) void emd_bid_finish_kernel(
   const int U = cnt[b];
   if (U == 0) return;
   const int ngroups = (U + 63) >> 6;
-  const BidSplit sp = bid_split(ngroups, G);
+  const BidSplit sp = bid_split(ngroups, G, n);
   if (sp.nb == 1) return;
   const int grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u = grp * 64 + lane;
@@ -448,7 +614,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
     float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     float *__restrict__ max_inc, const int *__restrict__ max_idx, const int *__restrict__ list,
     const int *__restrict__ cnt, int *__restrict__ list_next, int *__restrict__ cnt_next,
-    float *__restrict__ tgt_stream, int last) {
+    f4 *__restrict__ tgt4, int last) {
   const int b = blockIdx.y;
   const int U = cnt[b];
   const size_t o = (size_t)b * n;
@@ -465,7 +631,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       assignment[o + j] = tgt;
       const float np = price[o + tgt] + bid_inc[o + j];
       price[o + tgt] = np;
-      tgt_stream[o * 4 + tgt_slot(tgt, 3)] = filter_target(np);  // keep the bid filter in sync
+      reinterpret_cast<float *>(tgt4 + o + tgt)[3] = filter_target(np);  // keep the bid filter in sync
       max_inc[o + tgt] = -1e9f;
     } else {
       list_next[o + atomicAdd(&cnt_next[b], 1)] = j;
@@ -523,7 +689,12 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
   ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
   ws.cnt[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
-  ws.tgt = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.tgt4 = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.mstream = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.tperm = reinterpret_cast<int *>(p); p += arr;
+  ws.cell_of = reinterpret_cast<int *>(p); p += arr;
+  ws.hist = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
+  ws.bbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
   ws.partial = reinterpret_cast<float *>(p);
   return ws;
 }
@@ -532,8 +703,9 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 9 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
-         sn::align_up((size_t)b * n * 16, 256) + (size_t)b * 16 * 4 * 64 * 16;
+  return 11 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+         2 * sn::align_up((size_t)b * n * 16, 256) + (size_t)b * kSortCells * 4 +
+         sn::align_up((size_t)b * 24, 256) + (size_t)b * 16 * 4 * 64 * 16;
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
@@ -551,7 +723,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
+  cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz2, ws.bbox, ws.hist, ws.cell_of);
+  cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist, ws.tperm, total);
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
+  emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
   const int g_env = kBlocksPerCloud;
   const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
@@ -559,15 +734,18 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     const int c = it & 1;
     const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx,
                        reinterpret_cast<float4 *>(ws.partial)};
+    // prices move by bid increments >= eps per iteration: a lower bound for every price
+    const float price_floor = eps < 0.f ? eps * (float)it : 0.f;
     SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
-        b, g_env, n, eps, xyz1, xyz2, ws.price, ws.tgt, ws.list[c], ws.cnt[c], bo, stats)));
+        b, g_env, n, eps, price_floor, xyz1, ws.price, ws.tgt4, ws.mstream, ws.bbox, ws.tperm,
+        ws.list[c], ws.cnt[c], bo, stats)));
     emd_bid_finish_kernel<<<b, kBidThreads, 0, s>>>(g_env, n, eps, ws.list[c], ws.cnt[c], bo);
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.cnt[c ^ 1]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
                                                     ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.list[c ^ 1],
-                                                    ws.cnt[c ^ 1], ws.tgt, it == iters - 1);
+                                                    ws.cnt[c ^ 1], ws.tgt4, it == iters - 1);
   }
   emd_calcdist_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, assignment, dist);
   return sn::launch_status("sn_emd_forward");

@@ -18,6 +18,7 @@
 // (float)((double)temp + w) equals the plain fp32 sum for every pair of floats
 // (the double sum is exact unless w < ulp(temp)/32, where both round to temp), so
 // the accumulation stays in fp32.
+#include "cloud_sort.hpp"
 #include "common.hpp"
 #include "../../include/sn_expf.h"
 
@@ -167,108 +168,6 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
   const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
   const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
   return umin32(umin32(a, b), umin32(c, d));
-}
-
-constexpr int kMdsCells = 4096;  // 16^3 Morton cells for the counting sort
-
-__device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigned z) {
-  unsigned r = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    r |= (((x >> i) & 1u) << (3 * i)) | (((y >> i) & 1u) << (3 * i + 1)) | (((z >> i) & 1u) << (3 * i + 2));
-  return r;
-}
-
-// per cloud: bounding box -> cell histogram (one workgroup per cloud)
-__global__ __launch_bounds__(1024) void mds_sort_count_kernel(int n, const float *__restrict__ xyz,
-                                                              float *__restrict__ bbox,
-                                                              int *__restrict__ hist,
-                                                              int *__restrict__ cell_of) {
-  __shared__ float red[6][16];
-  __shared__ int lh[kMdsCells];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float *p = xyz + (size_t)b * n * 3;
-  float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
-  for (int k = tid; k < n; k += 1024)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = p[k * 3 + a];
-      lo[a] = __builtin_fminf(lo[a], v);
-      hi[a] = __builtin_fmaxf(hi[a], v);
-    }
-#pragma unroll
-  for (int a = 0; a < 3; ++a)
-    for (int m = 1; m < 64; m <<= 1) {
-      lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], m));
-      hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], m));
-    }
-  if ((tid & 63) == 0)
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      red[a][tid >> 6] = lo[a];
-      red[3 + a][tid >> 6] = hi[a];
-    }
-  for (int c = tid; c < kMdsCells; c += 1024) lh[c] = 0;
-  __syncthreads();
-  float blo[3], scale[3];
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    float l = red[a][0], h = red[3 + a][0];
-    for (int w = 1; w < 16; ++w) {
-      l = __builtin_fminf(l, red[a][w]);
-      h = __builtin_fmaxf(h, red[3 + a][w]);
-    }
-    blo[a] = l;
-    scale[a] = h > l ? 15.999f / (h - l) : 0.f;
-    if (tid == 0) {
-      bbox[b * 6 + a] = l;
-      bbox[b * 6 + 3 + a] = h;
-    }
-  }
-  for (int k = tid; k < n; k += 1024) {
-    unsigned q[3];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float f = (p[k * 3 + a] - blo[a]) * scale[a];
-      q[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
-    }
-    const int c = (int)morton3_4bit(q[0], q[1], q[2]);
-    cell_of[(size_t)b * n + k] = c;
-    atomicAdd(&lh[c], 1);
-  }
-  __syncthreads();
-  // exclusive scan of the 4096 cell counts (4 per lane) -> start offsets
-  const int c0 = tid * 4;
-  const int v0 = lh[c0], v1 = lh[c0 + 1], v2 = lh[c0 + 2], v3 = lh[c0 + 3];
-  int sum = v0 + v1 + v2 + v3, incl = sum;
-  for (int m = 1; m < 64; m <<= 1) {
-    const int o = __shfl_up(incl, m);
-    if ((tid & 63) >= m) incl += o;
-  }
-  __shared__ int wsum[16];
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
-  int ex = base + incl - sum;
-  int *h = hist + (size_t)b * kMdsCells;
-  h[c0] = ex;
-  h[c0 + 1] = ex + v0;
-  h[c0 + 2] = ex + v0 + v1;
-  h[c0 + 3] = ex + v0 + v1 + v2;
-}
-
-// scatter: perm[sorted position] = original index (order inside a cell is irrelevant)
-__global__ __launch_bounds__(256) void mds_sort_scatter_kernel(int n, const int *__restrict__ cell_of,
-                                                               int *__restrict__ hist,
-                                                               int *__restrict__ perm, long total) {
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
-    const long b = e / n;
-    const int k = (int)(e - b * n);
-    const int pos = atomicAdd(&hist[b * kMdsCells + cell_of[e]], 1);
-    perm[b * n + pos] = k;
-  }
 }
 
 // sn_expf (include/sn_expf.h) for arguments x <= 0 (or NaN): the same correctly rounded
@@ -569,7 +468,7 @@ static bool mds_use_clustered(int n) {
 extern "C" size_t sn_mds_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
   if (mds_use_clustered(n))  // perm + cell ids + cell offsets + bounding boxes
-    return sn::align_up((size_t)b * n * 4, 256) * 2 + (size_t)b * kMdsCells * 4 + 256 * (size_t)b;
+    return sn::align_up((size_t)b * n * 4, 256) * 2 + (size_t)b * kSortCells * 4 + 256 * (size_t)b;
   int bs = 1;
   while (bs * 2 <= n && bs < 1024) bs *= 2;
   return (n + bs - 1) / bs <= 24 ? 0 : (size_t)b * n * 4;
@@ -595,11 +494,11 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     char *w = static_cast<char *>(workspace);
     int *perm = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
     int *cell_of = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
-    int *hist = reinterpret_cast<int *>(w); w += (size_t)b * kMdsCells * 4;
+    int *hist = reinterpret_cast<int *>(w); w += (size_t)b * kSortCells * 4;
     float *bbox = reinterpret_cast<float *>(w);
-    mds_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz, bbox, hist, cell_of);
+    cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz, bbox, hist, cell_of);
     const long total = (long)b * n;
-    mds_sort_scatter_kernel<<<lin_blocks(total), 256, 0, s>>>(n, cell_of, hist, perm, total);
+    cloud_sort_scatter_kernel<<<lin_blocks(total), 256, 0, s>>>(n, cell_of, hist, perm, total);
     const size_t lds = (size_t)ppt * 1024 * 8;
 #define SN_MDSC(P)                                                                               \
   {                                                                                              \

@@ -8,11 +8,11 @@ B, N = 32, 16384
 g = torch.Generator().manual_seed(1234)
 x = torch.rand(B, N, 3, generator=g).to(dev); y = torch.rand(B, N, 3, generator=g).to(dev)
 lib = _lib.lib()
-for iters in ((1,) if os.environ.get("SN_EMD_DEBUG") == "1" else (1, 50)):
+for iters in (1, 50):
     emd_forward_raw(x, y, 0.005, iters); torch.cuda.synchronize()
     lib.sn_prof_reset(); lib.sn_prof_enable(1)
     for _ in range(3):
         emd_forward_raw(x, y, 0.005, iters)
     torch.cuda.synchronize(); lib.sn_prof_enable(0)
     ms = ctypes.c_double(0); n = lib.sn_prof_read(b"emd_bid", ctypes.byref(ms))
-    print(f"SN_EMD_DEBUG={os.environ.get('SN_EMD_DEBUG','0')} iters={iters}: bid total {ms.value/3:.3f} ms per call over {n//3} launches")
+    print(f"iters={iters}: bid total {ms.value/3:.3f} ms per call over {n//3} launches")

@@ -2,6 +2,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])  # A/B a saved build
 from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
 from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyFunction
 
@@ -22,6 +24,7 @@ for it in (1, 50):
     ms = s.elapsed_time(e) / K
     pairs = st[0].item() / K
     print(f"emd iters={it}: {ms:.3f} ms  pairs_eff={pairs:.3e}  {pairs/ms/1e9:.3f} Tpairs/s  active_iters={st[1].item()/K}")
+if os.environ.get("EMD_ONLY"): sys.exit(0)
 for _ in range(2):
     expansionPenaltyFunction.apply(x, 512, 1.5)
 torch.cuda.synchronize()
