@@ -143,6 +143,19 @@ int sn_p2i_max_forward(const float *points, const float *feat,
                        int npoints, int channels, int batch, int h, int w,
                        float radius, float *out, int *out_ids, void *workspace,
                        size_t workspace_bytes, void *stream);
+/* Several kernel radii over the same points / features / background in one pass
+ * (ComputeDepthMaps calls p2i once per radius with identical inputs,
+ * utils/p2i_utils.py:230-251): radii[nradii] is a HOST array, 1 <= nradii <= 4;
+ * out / out_ids hold nradii consecutive [batch,channels,h,w] tensors, each equal
+ * to what sn_p2i_max_forward returns for that radius. */
+size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels,
+                                        int h, int w);
+int sn_p2i_max_forward_multi(const float *points, const float *feat,
+                             const int *batch_inds, const float *background,
+                             int npoints, int channels, int batch, int h, int w,
+                             const float *radii, int nradii, float *out,
+                             int *out_ids, void *workspace,
+                             size_t workspace_bytes, void *stream);
 /* points_grad[npoints,2], feat_grad[npoints,channels],
  * background_grad[batch,channels,h,w] are fully overwritten.
  * batch_inds: the forward's batch_inds, or NULL (the reference's backward does not

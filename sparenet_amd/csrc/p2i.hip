@@ -20,6 +20,9 @@
 //     of a wave fall into few cache lines, and the double-precision cosine work
 //     of a point (up to ~314 pixels at R=10) is shared by 16-32 lanes instead of
 //     one thread.
+#include <cmath>
+#include <cstring>
+
 #include "common.hpp"
 
 namespace {
@@ -221,6 +224,258 @@ __global__ __launch_bounds__(256) void p2i_max_splat_kernel(
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (lane < qn) splat_exact(q[lane], img, radius);
+}
+
+// ---------------------------------------------------------------------------------------
+// Binned gather (the production path for kernel radii <= 16 px; several radii per pass).
+// The scatter above pays an L2 round trip per pixel hit (the pruning read), a device-scope
+// atomic per survivor, and wastes lanes on the box corners.  The gather turns the loop inside
+// out: points are binned once into 8x8-pixel cells (counting sort, one entry per point); one
+// WAVE owns an 8x8 tile, lane = pixel, and walks the points of the (2H+1)^2 surrounding cells,
+// H = floor(Rmax / 8) + 1.  A cell row of an image is contiguous in the sorted arrays, so the
+// candidates arrive as 2H+1 ranges, fetched 64 at a time (one per lane) and broadcast with
+// v_readlane.  The running best of every pixel stays in registers; a candidate is only
+// evaluated exactly (fp64 cosine) when a cheap fp32 upper bound of feature*weight reaches the
+// pixel's current best -- those pairs go to a per-wave LDS queue and are drained 64 at a
+// time, the result meeting the pixel through a packed 64-bit LDS atomicMax (value bits << 32
+// | ~id), so equal values still resolve to the lowest point id and nothing depends on the
+// visiting order.  All radii of a ComputeDepthMaps call share the binning, the fetches and the
+// squared distances; the finished tile is written once as values + ids.
+// ---------------------------------------------------------------------------------------
+constexpr int kCell = 8;
+constexpr int kMaxRadii = 4;
+
+struct RadiiArg {
+  float radius[kMaxRadii], s_max[kMaxRadii], rev_scale[kMaxRadii];
+  float s_max_all;  // largest s_max
+  int halo;         // cells to look at on each side
+};
+
+// cell of a point = cell of its centre clamped into the image (a point outside the image can
+// only reach pixels within R of the border, which the halo covers); -1: cannot reach any pixel
+__device__ __forceinline__ int cell_of_point(float py, float px, int h, int w, int cells_x,
+                                             int cells_y) {
+  if (!(__builtin_fabsf(py) < 1e9f) || !(__builtin_fabsf(px) < 1e9f)) return -1;  // NaN / inf
+  const int cy = clampi((int)floorf(py) / kCell, 0, cells_y - 1);
+  const int cx = clampi((int)floorf(px) / kCell, 0, cells_x - 1);
+  (void)h;
+  (void)w;
+  return cy * cells_x + cx;
+}
+
+__global__ __launch_bounds__(256) void p2i_bin_count_kernel(
+    const float *__restrict__ points, const int *__restrict__ batch_inds, int *__restrict__ offs,
+    int npoints, int batch, int h, int w, int cells_x, int cells_y) {
+  for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
+       pid += gridDim.x * blockDim.x) {
+    const int b = batch_inds[pid];
+    if (b < 0 || b >= batch) continue;
+    const int c = cell_of_point(points[pid * 2 + 0], points[pid * 2 + 1], h, w, cells_x, cells_y);
+    if (c >= 0) atomicAdd(&offs[b * cells_y * cells_x + c], 1);
+  }
+}
+
+// in-place exclusive scan of the cell counts (one workgroup)
+__global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(int *__restrict__ offs, int T) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < T; base += 1024) {
+    const int i = base + tid;
+    const int v = i < T ? offs[i] : 0;
+    int incl = v;
+    for (int m = 1; m < 64; m <<= 1) {
+      const int o = __shfl_up(incl, m);
+      if ((tid & 63) >= m) incl += o;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int wv = 0; wv < (tid >> 6); ++wv) pre += wsum[wv];
+    if (i < T) offs[i] = pre + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+}
+
+// sorted payload: spt[pos] = (row, col), sid[pos] = point id; afterwards offs[c] is the END of cell c
+__global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
+    const float *__restrict__ points, const int *__restrict__ batch_inds, int *__restrict__ offs,
+    float2 *__restrict__ spt, int *__restrict__ sid, int npoints, int batch, int h, int w,
+    int cells_x, int cells_y) {
+  for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
+       pid += gridDim.x * blockDim.x) {
+    const int b = batch_inds[pid];
+    if (b < 0 || b >= batch) continue;
+    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+    const int c = cell_of_point(py, px, h, w, cells_x, cells_y);
+    if (c < 0) continue;
+    const int pos = atomicAdd(&offs[b * cells_y * cells_x + c], 1);
+    spt[pos] = make_float2(py, px);
+    sid[pos] = pid;
+  }
+}
+
+struct GatherHit {
+  unsigned lane_k;  // pixel lane | radius index << 6
+  float s, f;       // dx*dx+dy*dy, feature
+  unsigned low;     // 0xFFFFFFFE - point id
+};
+
+template <int NR>
+__global__ __launch_bounds__(256) void p2i_gather_max_kernel(
+    const float *__restrict__ feat, const float *__restrict__ background,
+    const float2 *__restrict__ spt, const int *__restrict__ sid, const int *__restrict__ offs,
+    int channels, int batch, int h, int w, int cells_x, int cells_y, RadiiArg ra,
+    float *__restrict__ out, int *__restrict__ out_ids) {
+  constexpr int kQ = 128;
+  __shared__ unsigned long long slot[4][NR][64];
+  __shared__ GatherHit queue[4][kQ];
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  GatherHit *q = queue[wave];
+  long tile = (long)blockIdx.x * 4 + wave;  // (b, c, cy, cx), cx fastest
+  const long tiles = (long)batch * channels * cells_y * cells_x;
+  if (tile >= tiles) return;  // whole wave; no workgroup barrier below
+  const int cx = (int)(tile % cells_x); tile /= cells_x;
+  const int cy = (int)(tile % cells_y); tile /= cells_y;
+  const int c = (int)(tile % channels);
+  const int b = (int)(tile / channels);
+  const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
+  const bool valid = x < w && y < h;
+  const size_t plane = ((size_t)b * channels + c) * h * w;
+  const float fx = (float)x, fy = (float)y;
+  float best[NR];  // the pixel's current exact value, refreshed after every drain
+  {
+    const float bg = valid ? background[plane + (size_t)y * w + x] : 0.f;
+    const unsigned long long key = ((unsigned long long)ord_f32(bg) << 32) | 0xFFFFFFFFull;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      slot[wave][k][lane] = key;
+      best[k] = bg;
+    }
+  }
+  const float tx0 = (float)(cx * kCell), tx1 = tx0 + (kCell - 1), ty0 = (float)(cy * kCell),
+              ty1 = ty0 + (kCell - 1);
+  float tile_min[NR];  // wave-uniform: smallest current best over the tile's pixels
+  int qn = 0;  // wave-uniform queue fill
+  auto refresh_tile_min = [&]() {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      float m = valid ? best[k] : 3.0e38f;
+      for (int sft = 1; sft < 64; sft <<= 1) m = __builtin_fminf(m, __shfl_xor(m, sft));
+      tile_min[k] = m;
+    }
+  };
+  refresh_tile_min();
+  auto drain = [&](int first, int count) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < count) {
+      const GatherHit hh = q[first + lane];
+      const int k = (int)(hh.lane_k >> 6);
+      float radius = ra.radius[0];
+#pragma unroll
+      for (int i = 1; i < NR; ++i) radius = k == i ? ra.radius[i] : radius;
+      const float v = hh.f * cos_weight(__builtin_sqrtf(hh.s), radius);
+      atomicMax(&slot[wave][k][hh.lane_k & 63u], ((unsigned long long)ord_f32(v) << 32) | hh.low);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NR; ++k) best[k] = unord_f32((unsigned)(slot[wave][k][lane] >> 32));
+    refresh_tile_min();
+  };
+
+  const int cell_base = b * cells_y * cells_x;
+  for (int step = 0; step <= 2 * ra.halo; ++step) {
+    // rows nearest first: 0, -1, +1, -2, +2, ... so that the best values grow early
+    const int cyy = cy + ((step & 1) ? -((step + 1) >> 1) : (step >> 1));
+    if (cyy < 0 || cyy >= cells_y) continue;  // wave-uniform
+    const int c_lo = cx - ra.halo > 0 ? cx - ra.halo : 0;
+    const int c_hi = cx + ra.halo < cells_x - 1 ? cx + ra.halo : cells_x - 1;
+    const int first_cell = cell_base + cyy * cells_x + c_lo;
+    const int beg = first_cell > 0 ? offs[first_cell - 1] : 0;
+    const int end = offs[cell_base + cyy * cells_x + c_hi];
+    for (int base = beg; base < end; base += 64) {
+      const int j = base + lane;
+      float cpy = 0.f, cpx = 0.f, cf = 0.f;
+      unsigned clow = 0;
+      if (j < end) {
+        const float2 pt = spt[j];
+        const int pid = sid[j];
+        cpy = pt.x;
+        cpx = pt.y;
+        cf = feat[(size_t)pid * channels + c];
+        clow = 0xFFFFFFFEu - (unsigned)pid;
+      }
+      // Cull, 64 candidates at a time (lane = candidate): nearest pixel of the tile out of
+      // range, or even there the bound cannot reach the smallest current best of the tile.
+      unsigned long long keep[NR];
+      {
+        const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
+        const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
+        const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
+        const float rmin = __builtin_amdgcn_sqrtf(smin) * 0.99999f;
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const float wq = __builtin_amdgcn_cosf(rmin * ra.rev_scale[k]) * 0.5f + 0.5f + 4e-5f;
+          const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
+          keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub >= tile_min[k]);
+        }
+      }
+      unsigned long long todo = keep[0];
+#pragma unroll
+      for (int k = 1; k < NR; ++k) todo |= keep[k];
+      while (todo) {  // wave-uniform: candidate i broadcast to every pixel
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpy), i));
+        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpx), i));
+        const float dx = fx - px, dy = fy - py;
+        const float s2 = sq2(dx, dy);
+        const float f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), i));
+        const float rad = __builtin_amdgcn_sqrtf(s2);  // ~1 ulp: only feeds the bound
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
+          const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
+          const float wq = __builtin_amdgcn_cosf(rad * ra.rev_scale[k]) * 0.5f + 0.5f;
+          const float ub = f >= 0.f ? f * (wq + 2e-5f) : f * __builtin_fmaxf(wq - 2e-5f, 0.f);
+          const bool pass = ink && ub >= best[k];  // can still reach (or tie with) the best
+          const unsigned long long m = __ballot(pass);
+          if (m) {
+            if (pass)
+              q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
+                  GatherHit{(unsigned)lane | ((unsigned)k << 6), s2, f,
+                            (unsigned)__builtin_amdgcn_readlane((int)clow, i)};
+            qn += __popcll(m);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            if (qn >= 64) {
+              qn -= 64;
+              drain(qn, 64);
+            }
+          }
+        }
+      }
+    }
+    if (step == 0 && qn > 0) {  // the tile's own cell row: establish the bests early
+      drain(0, qn);
+      qn = 0;
+    }
+  }
+  if (qn > 0) drain(0, qn);
+  if (valid) {
+    const size_t image = (size_t)batch * channels * h * w;  // one output tensor per radius
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const unsigned long long key = slot[wave][k][lane];
+      const unsigned lw = (unsigned)key;
+      const size_t e = k * image + plane + (size_t)y * w + x;
+      out[e] = unord_f32((unsigned)(key >> 32));
+      out_ids[e] = lw == 0xFFFFFFFFu ? -1 : (int)(0xFFFFFFFEu - lw);
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void p2i_max_finalize_kernel(
@@ -453,6 +708,91 @@ extern "C" size_t sn_p2i_max_workspace_bytes(int batch, int channels, int h, int
   return (size_t)batch * channels * h * w * 8;
 }
 
+namespace {
+
+constexpr float kTileMaxRadius = 16.f;  // larger kernels use the global scatter
+
+size_t tile_workspace_bytes(int npoints, int batch, int h, int w) {
+  const size_t cells = (size_t)batch * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);
+  return sn::align_up(cells * 4, 256) + sn::align_up((size_t)npoints * 8, 256) + (size_t)npoints * 4;
+}
+
+// largest fp32 s with sqrtf(s) <= radius, on the host (IEEE sqrtf is correctly rounded there too)
+float max_sq_inside_host(float radius) {
+  volatile float s = radius * radius;
+  auto next = [](float v, int d) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u += d;
+    memcpy(&v, &u, 4);
+    return v;
+  };
+  while (sqrtf(s) > radius) s = next(s, -1);
+  for (;;) {
+    const float t = next(s, 1);
+    if (!(sqrtf(t) <= radius)) break;
+    s = t;
+  }
+  return s;
+}
+
+// values + ids of nradii splats that share points / features / background (radii <= 16 px)
+int tile_forward(const char *fn, const float *points, const float *feat, const int *batch_inds,
+                 const float *background, int npoints, int channels, int batch, int h, int w,
+                 const float *radii, int nradii, float *out, int *out_ids, void *workspace,
+                 hipStream_t s) {
+  RadiiArg ra = {};
+  float rmax = 0.f;
+  for (int k = 0; k < nradii; ++k) {
+    ra.radius[k] = radii[k];
+    ra.s_max[k] = max_sq_inside_host(radii[k]);
+    ra.rev_scale[k] = 0.5f / radii[k];  // r*pi/R radians = r/(2R) revolutions
+    ra.s_max_all = ra.s_max[k] > ra.s_max_all ? ra.s_max[k] : ra.s_max_all;
+    rmax = radii[k] > rmax ? radii[k] : rmax;
+  }
+  ra.halo = (int)floorf(rmax / kCell) + 1;
+  const int cells_x = sn::ceil_div(w, kCell), cells_y = sn::ceil_div(h, kCell);
+  const long cells = (long)batch * cells_x * cells_y;
+  const long tiles = cells * channels;
+  SN_REQUIRE(tiles / 4 + 1 < (1L << 31), "%s: too many tiles", fn);
+  char *wp = static_cast<char *>(workspace);
+  int *offs = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
+  float2 *spt = reinterpret_cast<float2 *>(wp); wp += sn::align_up((size_t)npoints * 8, 256);
+  int *sid = reinterpret_cast<int *>(wp);
+  SN_HIP(hipMemsetAsync(offs, 0, (size_t)cells * 4, s));
+  if (npoints > 0) {
+    p2i_bin_count_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, offs, npoints, batch,
+                                                             h, w, cells_x, cells_y);
+    p2i_bin_scan_kernel<<<1, 1024, 0, s>>>(offs, (int)cells);
+    p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, offs, spt, sid,
+                                                               npoints, batch, h, w, cells_x, cells_y);
+  }
+  const int blocks = (int)((tiles + 3) / 4);
+#define SN_GATHER(NR)                                                                         \
+  p2i_gather_max_kernel<NR><<<blocks, 256, 0, s>>>(feat, background, spt, sid, offs, channels, \
+      batch, h, w, cells_x, cells_y, ra, out, out_ids)
+  if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
+  switch (nradii) {
+    case 1: SN_GATHER(1); break;
+    case 2: SN_GATHER(2); break;
+    case 3: SN_GATHER(3); break;
+    default: SN_GATHER(4); break;
+  }
+  if (sn::prof_enabled()) sn::prof_end("p2i_max_splat", s);
+#undef SN_GATHER
+  return sn::launch_status(fn);
+}
+
+}  // namespace
+
+extern "C" size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels, int h,
+                                                   int w) {
+  if (npoints < 0 || batch < 1 || channels < 1 || h < 1 || w < 1) return 0;
+  const size_t a = sn_p2i_max_workspace_bytes(batch, channels, h, w);
+  const size_t t = tile_workspace_bytes(npoints, batch, h, w);
+  return a > t ? a : t;
+}
+
 extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const int *batch_inds,
                                   const float *background, int npoints, int channels, int batch,
                                   int h, int w, float radius, float *out, int *out_ids,
@@ -463,6 +803,9 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
   SN_REQUIRE(workspace_bytes >= sn_p2i_max_workspace_bytes(batch, channels, h, w),
              "sn_p2i_max_forward: workspace too small");
   hipStream_t s = sn::as_stream(stream);
+  if (radius <= kTileMaxRadius && workspace_bytes >= tile_workspace_bytes(npoints, batch, h, w))
+    return tile_forward("sn_p2i_max_forward", points, feat, batch_inds, background, npoints,
+                        channels, batch, h, w, &radius, 1, out, out_ids, workspace, s);
   unsigned long long *img = static_cast<unsigned long long *>(workspace);
   const long px = (long)batch * channels * h * w;
   p2i_max_init_kernel<<<lin_blocks(px), 256, 0, s>>>(background, img, px);
@@ -487,6 +830,37 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
   }
   p2i_max_finalize_kernel<<<lin_blocks(px), 256, 0, s>>>(img, out, out_ids, px);
   return sn::launch_status("sn_p2i_max_forward");
+}
+
+extern "C" int sn_p2i_max_forward_multi(const float *points, const float *feat,
+                                        const int *batch_inds, const float *background,
+                                        int npoints, int channels, int batch, int h, int w,
+                                        const float *radii, int nradii, float *out, int *out_ids,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(background && out && out_ids && workspace && radii,
+             "sn_p2i_max_forward_multi: null pointer");
+  SN_REQUIRE(npoints == 0 || (points && feat && batch_inds), "sn_p2i_max_forward_multi: null pointer");
+  SN_REQUIRE(nradii >= 1 && nradii <= kMaxRadii, "sn_p2i_max_forward_multi: 1..%d radii (got %d)",
+             kMaxRadii, nradii);
+  float rmax = 0.f;
+  for (int k = 0; k < nradii; ++k) {
+    if (int rc = check_common("sn_p2i_max_forward_multi", npoints, channels, batch, h, w, radii[k]))
+      return rc;
+    rmax = radii[k] > rmax ? radii[k] : rmax;
+  }
+  SN_REQUIRE(workspace_bytes >= sn_p2i_max_multi_workspace_bytes(npoints, batch, channels, h, w),
+             "sn_p2i_max_forward_multi: workspace too small");
+  hipStream_t s = sn::as_stream(stream);
+  if (rmax <= kTileMaxRadius)
+    return tile_forward("sn_p2i_max_forward_multi", points, feat, batch_inds, background, npoints,
+                        channels, batch, h, w, radii, nradii, out, out_ids, workspace, s);
+  const size_t image = (size_t)batch * channels * h * w;
+  for (int k = 0; k < nradii; ++k)  // large kernels: one global splat per radius
+    if (int rc = sn_p2i_max_forward(points, feat, batch_inds, background, npoints, channels, batch,
+                                    h, w, radii[k], out + k * image, out_ids + k * image,
+                                    workspace, workspace_bytes, stream))
+      return rc;
+  return 0;
 }
 
 extern "C" size_t sn_p2i_max_backward_workspace_bytes(int batch, int channels, int h, int w) {

@@ -49,6 +49,31 @@ class _Ext:
         return out, ids
 
     @staticmethod
+    def p2i_max_forward_multi_gpu(points, point_features, batch_inds, background, kernel_kind,
+                                  radii):
+        """All radii of one ComputeDepthMaps call in one pass (sn_p2i_max_forward_multi):
+        returns out / ids of shape [len(radii), batch, channels, h, w]."""
+        if kernel_kind != 0:
+            raise ValueError("p2i: only kernel_kind 0 ('cos') exists")
+        n, c, b, h, w = _shapes(points, point_features, background)
+        nr = len(radii)
+        out = torch.empty((nr,) + tuple(background.shape), dtype=background.dtype,
+                          device=background.device)
+        ids = torch.empty(out.shape, dtype=torch.int32, device=background.device)
+        host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
+        with torch.cuda.device_of(background):
+            nbytes = _lib.lib().sn_p2i_max_multi_workspace_bytes(n, b, c, h, w)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=background.device)
+            code = _lib.lib().sn_p2i_max_forward_multi(
+                _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
+                _lib.iptr(batch_inds, "batch_inds"), _lib.fptr(background, "background"),
+                n, c, b, h, w, host_radii, nr, _lib.fptr(out, "out"),
+                _lib.iptr(ids, "out_point_ids"), ctypes.c_void_p(ws.data_ptr()),
+                ctypes.c_size_t(nbytes), _lib.stream_of(background))
+        _lib.check(code, "sn_p2i_max_forward_multi")
+        return out, ids
+
+    @staticmethod
     def p2i_max_backward_gpu(out_grad, out_point_ids, points, point_features, kernel_kind,
                              kernel_radius, batch_inds=None):
         n = points.size(0)
@@ -147,6 +172,34 @@ class P2IMaxFunction(Function):
         g_points, g_feat, g_bg = ext.p2i_max_backward_gpu(
             out_grad.contiguous(), winner_ids, *_c(points, point_features), *ctx.kind_radius,
             batch_inds=batch_inds)
+        return g_points, g_feat, None, g_bg, None, None
+
+
+class P2IMaxMultiFunction(Function):
+    """P2IMaxFunction for several kernel radii at once: returns [len(radii), B, C, H, W], slice
+    r equal to P2IMaxFunction.apply(..., radii[r]).  The forward shares one binning and one
+    pixel walk between the radii; the backward is the per-radius backward, summed."""
+
+    @staticmethod
+    def forward(ctx, points, point_features, batch_inds, background, kernel_kind, radii):
+        out, winner_ids = ext.p2i_max_forward_multi_gpu(
+            *_c(points, point_features, batch_inds, background), kernel_kind, radii)
+        ctx.save_for_backward(points, point_features, winner_ids, batch_inds.contiguous())
+        ctx.kind_radii = (kernel_kind, tuple(float(r) for r in radii))
+        return out
+
+    @staticmethod
+    def backward(ctx, out_grad):
+        points, point_features, winner_ids, batch_inds = ctx.saved_tensors
+        kind, radii = ctx.kind_radii
+        pts, feats = _c(points, point_features)
+        g_points = g_feat = g_bg = None
+        for r, radius in enumerate(radii):
+            gp, gf, gb = ext.p2i_max_backward_gpu(out_grad[r].contiguous(), winner_ids[r], pts,
+                                                  feats, kind, radius, batch_inds=batch_inds)
+            g_points = gp if g_points is None else g_points + gp
+            g_feat = gf if g_feat is None else g_feat + gf
+            g_bg = gb if g_bg is None else g_bg + gb
         return g_points, g_feat, None, g_bg, None, None
 
 

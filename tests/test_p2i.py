@@ -120,6 +120,50 @@ def test_hip_max_matches_oracle(B, n, C, S, R, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,n,C,H,W,radii", [(2, 3000, 1, 64, 64, [5.0, 7.0, 10.0]),
+                                             (3, 2000, 2, 50, 70, [10.0, 3.0]),
+                                             (1, 500, 1, 33, 31, [16.0, 0.7, 2.5, 9.0]),
+                                             (2, 1500, 1, 48, 48, [20.0, 5.0])])
+def test_hip_multi_radius_matches_oracle_and_single(B, n, C, H, W, radii, dev):
+    """sn_p2i_max_forward_multi (tile-binned, all radii in one pass; radii > 16 px fall back to
+    the global splat) == one single-radius call per radius == the oracle; shuffled batch ids
+    and points outside the image included."""
+    from sparenet_amd.cuda.p2i_op import ext
+
+    g = torch.Generator().manual_seed(B * 1000 + n)
+    pts = (torch.rand(B * n, 2, generator=g) * 1.3 - 0.15) * torch.tensor([H - 1.0, W - 1.0])
+    feat = torch.rand(B * n, C, generator=g) - 0.2
+    bi = torch.randint(-1, B + 1, (B * n,), generator=g).to(torch.int32)   # some ids out of range
+    bg = torch.rand(B, C, H, W, generator=g) * 0.1
+    out, ids = ext.p2i_max_forward_multi_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, radii)
+    assert out.shape == (len(radii), B, C, H, W)
+    for r, R in enumerate(radii):
+        o1, i1 = ext.p2i_max_forward_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, R)
+        assert torch.equal(out[r], o1) and torch.equal(ids[r], i1), R
+        o, i = oracle.p2i_max_forward(pts.numpy(), feat.numpy(), bi.numpy(), bg.numpy(), R)
+        _close_maps(out[r].cpu().numpy(), ids[r].cpu().numpy(), o, i, f"multi R={R}")
+
+
+@pytest.mark.gpu
+def test_hip_multi_radius_autograd_is_sum_of_singles(dev):
+    from sparenet_amd.cuda.p2i_op import P2IMaxFunction, P2IMaxMultiFunction
+
+    g = torch.Generator().manual_seed(5)
+    B, n, S, radii = 2, 800, 40, [3.0, 6.0, 9.0]
+    pts0 = (torch.rand(B * n, 2, generator=g) * (S - 1)).to(dev)
+    feat0 = torch.rand(B * n, 1, generator=g).to(dev)
+    bi = torch.arange(B, dtype=torch.int32).repeat_interleave(n).to(dev)
+    bg = torch.zeros(B, 1, S, S, device=dev)
+    wgt = torch.rand(len(radii), B, 1, S, S, generator=g).to(dev)
+    p1, f1 = pts0.clone().requires_grad_(True), feat0.clone().requires_grad_(True)
+    (P2IMaxMultiFunction.apply(p1, f1, bi, bg, 0, radii) * wgt).sum().backward()
+    p2, f2 = pts0.clone().requires_grad_(True), feat0.clone().requires_grad_(True)
+    sum((P2IMaxFunction.apply(p2, f2, bi, bg, 0, R) * wgt[r]).sum() for r, R in enumerate(radii)).backward()
+    np.testing.assert_allclose(p1.grad.cpu().numpy(), p2.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(f1.grad.cpu().numpy(), f2.grad.cpu().numpy(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
 def test_hip_ties_pick_lowest_point_id(dev):
     """Duplicated points produce bit-equal splat values: the lowest id must win; a point
     whose value merely equals the background must not replace it (id stays -1)."""
