@@ -168,6 +168,19 @@ int sn_p2i_max_backward(const float *out_grad, const int *out_ids,
                         float *points_grad, float *feat_grad,
                         float *background_grad, void *workspace,
                         size_t workspace_bytes, void *stream);
+/* Backward of nradii splats that share points / features (the gradients of the radii
+ * are summed, which is what autograd does with the reference's per-radius calls).
+ * out_grad / out_ids: nradii consecutive [batch,channels,h,w] tensors.  Pixel-centric:
+ * every pixel adds its terms to its winner in 64-bit fixed point (integer atomics), so
+ * the sums are exact and bit-reproducible. */
+size_t sn_p2i_max_backward_multi_workspace_bytes(int npoints, int channels);
+int sn_p2i_max_backward_multi(const float *out_grad, const int *out_ids,
+                              const float *points, const float *feat,
+                              int npoints, int channels, int batch, int h, int w,
+                              const float *radii, int nradii, float *points_grad,
+                              float *feat_grad, float *background_grad,
+                              void *workspace, size_t workspace_bytes,
+                              void *stream);
 /* replaces p2i_op.p2i_sum_forward_gpu / p2i_sum_backward_gpu
  *          (cuda/p2i_op/ext.cpp:6-7; p2i_sum.h:133-214; functors :7-131)
  * out must hold a copy of background on entry (the reference clones it,

@@ -701,6 +701,143 @@ int lin_blocks(long total) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// ---------------------------------------------------------------------------------------
+// max backward, pixel-centric with EXACT accumulation (all radii of a call in one pass).
+// Every pixel that has a winner adds its three terms (d feature, d row, d col) to the winner's
+// accumulators.  fp32 atomics would make the sums depend on the arrival order; instead the
+// terms are converted to 64-bit fixed point (scale = a power of two chosen on the device from
+// max|out_grad| and max|feature|) and added with integer atomics -- integer addition is
+// associative, so the result is bit-reproducible, and it equals the exactly rounded sum of the
+// fp32 terms to ~2^-45 of the largest possible term.  The XCD-aware map keeps all pixels of an
+// image, hence all atomics on its points, inside one XCD's L2.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void p2i_absmax_kernel(const float *__restrict__ a, long na,
+                                                         const float *__restrict__ b, long nb,
+                                                         unsigned *__restrict__ out2) {
+  float ma = 0.f, mb = 0.f;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < na; e += (long)gridDim.x * blockDim.x)
+    ma = __builtin_fmaxf(ma, __builtin_fabsf(a[e]));
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < nb; e += (long)gridDim.x * blockDim.x)
+    mb = __builtin_fmaxf(mb, __builtin_fabsf(b[e]));
+  for (int m = 1; m < 64; m <<= 1) {
+    ma = __builtin_fmaxf(ma, __shfl_xor(ma, m));
+    mb = __builtin_fmaxf(mb, __shfl_xor(mb, m));
+  }
+  __shared__ float red[2][4];
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = ma;
+    red[1][threadIdx.x >> 6] = mb;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {  // |x| >= 0: the bit patterns order like the values
+    for (int i = 1; i < 4; ++i) {
+      ma = __builtin_fmaxf(ma, red[0][i]);
+      mb = __builtin_fmaxf(mb, red[1][i]);
+    }
+    atomicMax(out2 + 0, __float_as_uint(ma));
+    atomicMax(out2 + 1, __float_as_uint(mb));
+  }
+}
+
+// 2^e with every |term| * 2^e < 2^44 (sums of < 2^18 terms stay inside int64)
+__device__ __forceinline__ double fixed_scale(const unsigned *absmax, float min_radius) {
+  const float g = __uint_as_float(absmax[0]), f = __uint_as_float(absmax[1]);
+  const float m = g * __builtin_fmaxf(1.f, f * (1.5707964f / min_radius) * 1.01f);
+  if (!(m > 0.f) || !(m < 3e38f)) return 1.0;
+  return ldexp(1.0, 43 - ilogbf(m));
+}
+
+constexpr int kAccSlots = 256;  // per-wave hash table: <= 64 pixels x 4 radii distinct winners
+
+__global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
+    const float *__restrict__ out_grad, const int *__restrict__ out_ids,
+    const float *__restrict__ points, const float *__restrict__ feat,
+    const unsigned *__restrict__ absmax, float *__restrict__ background_grad,
+    long long *__restrict__ acc_pts, long long *__restrict__ acc_feat, int channels, int batch,
+    int h, int w, RadiiArg ra, int nradii, float min_radius) {
+  // One wave per 8x8 tile (lane = pixel).  Neighbouring pixels, and the radii of one pixel,
+  // often share their winner: the terms first meet in a per-wave LDS hash table keyed by the
+  // point id (LDS integer atomics), and every distinct winner of the tile then costs three
+  // global atomics.  XCD-aware: workgroup g runs on XCD g % 8 and only touches images b with
+  // b % 8 == g % 8.
+  __shared__ int keys[4][kAccSlots];
+  __shared__ unsigned long long vals[4][kAccSlots][3];
+  const int cells_x = (w + kCell - 1) / kCell, cells_y = (h + kCell - 1) / kCell;
+  const long per_image = (long)channels * cells_y * cells_x;  // tiles
+  const int bpi = (int)((per_image + 3) / 4);                  // workgroups per image
+  const int g = blockIdx.x, xcd = g & 7, r = g >> 3;
+  const int b = (r / bpi) * 8 + xcd;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  long tile = (long)(r % bpi) * 4 + wave;
+  if (b >= batch || tile >= per_image) return;  // whole waves; no workgroup barrier below
+  const int cx = (int)(tile % cells_x); tile /= cells_x;
+  const int cy = (int)(tile % cells_y);
+  const int c = (int)(tile / cells_y);
+  const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
+  const bool valid = x < w && y < h;
+  const double scale = fixed_scale(absmax, min_radius);
+  const size_t plane = ((size_t)b * channels + c) * h * w;
+  const size_t e = plane + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
+  const long image = (long)batch * channels * h * w;
+  for (int i = lane; i < kAccSlots; i += 64) {
+    keys[wave][i] = -1;
+    vals[wave][i][0] = vals[wave][i][1] = vals[wave][i][2] = 0ull;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  float bg = 0.f;
+  for (int k = 0; k < nradii; ++k) {
+    const float gk = valid ? out_grad[k * image + e] : 0.f;
+    const int pid = valid ? out_ids[k * image + e] : -1;
+    if (pid < 0) {
+      bg += gk;
+      continue;
+    }
+    const float radius = ra.radius[k];
+    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+    const float dx = x - px, dy = y - py;
+    const float rr = radius_of(dx, dy);
+    const float wgt = cos_weight(rr, radius);
+    const float fv = feat[(size_t)pid * channels + c];
+    const float cf = gk * wgt;
+    const float wg = gk * fv;
+    const float rm = rr > 1e-10f ? rr : 1e-10f;
+    const float kk = (float)((double)wg * sin((double)rr * M_PI / (double)radius) * 0.5 * M_PI /
+                             (double)radius / (double)rm);
+    unsigned slot = ((unsigned)pid * 2654435761u) >> 24;  // 8 bits
+    for (;;) {  // <= 256 distinct winners per tile: the table cannot fill up
+      const int prev = atomicCAS(&keys[wave][slot], -1, pid);
+      if (prev == -1 || prev == pid) break;
+      slot = (slot + 1) & (kAccSlots - 1);
+    }
+    atomicAdd(&vals[wave][slot][0], (unsigned long long)llrint((double)cf * scale));
+    atomicAdd(&vals[wave][slot][1], (unsigned long long)llrint((double)(kk * dy) * scale));
+    atomicAdd(&vals[wave][slot][2], (unsigned long long)llrint((double)(kk * dx) * scale));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  for (int i = lane; i < kAccSlots; i += 64) {
+    const int id0 = keys[wave][i];
+    if (id0 < 0) continue;
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)id0 * channels + c), vals[wave][i][0]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 0), vals[wave][i][1]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 1), vals[wave][i][2]);
+  }
+  if (valid) background_grad[e] = bg;
+}
+
+__global__ __launch_bounds__(256) void p2i_max_bwd_finish_kernel(
+    const long long *__restrict__ acc_pts, const long long *__restrict__ acc_feat,
+    const unsigned *__restrict__ absmax, float *__restrict__ points_grad,
+    float *__restrict__ feat_grad, long npts2, long nfeat, float min_radius) {
+  const double inv = 1.0 / fixed_scale(absmax, min_radius);
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < npts2 + nfeat;
+       e += (long)gridDim.x * blockDim.x) {
+    if (e < npts2)
+      points_grad[e] = (float)((double)acc_pts[e] * inv);
+    else
+      feat_grad[e - npts2] = (float)((double)acc_feat[e - npts2] * inv);
+  }
+}
+
 }  // namespace
 
 extern "C" size_t sn_p2i_max_workspace_bytes(int batch, int channels, int h, int w) {
@@ -901,6 +1038,54 @@ extern "C" int sn_p2i_max_backward(const float *out_grad, const int *out_ids, co
 #undef SN_BWD
   }
   return sn::launch_status("sn_p2i_max_backward");
+}
+
+extern "C" size_t sn_p2i_max_backward_multi_workspace_bytes(int npoints, int channels) {
+  if (npoints < 0 || channels < 1) return 0;
+  return 256 + (size_t)npoints * (2 + (size_t)channels) * 8;
+}
+
+extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_ids,
+                                         const float *points, const float *feat, int npoints,
+                                         int channels, int batch, int h, int w, const float *radii,
+                                         int nradii, float *points_grad, float *feat_grad,
+                                         float *background_grad, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(out_grad && out_ids && background_grad && workspace && radii,
+             "sn_p2i_max_backward_multi: null pointer");
+  SN_REQUIRE(npoints == 0 || (points && feat && points_grad && feat_grad),
+             "sn_p2i_max_backward_multi: null pointer");
+  SN_REQUIRE(nradii >= 1 && nradii <= kMaxRadii, "sn_p2i_max_backward_multi: 1..%d radii (got %d)",
+             kMaxRadii, nradii);
+  RadiiArg ra = {};
+  float rmin = 3e38f;
+  for (int k = 0; k < nradii; ++k) {
+    if (int rc = check_common("sn_p2i_max_backward_multi", npoints, channels, batch, h, w, radii[k]))
+      return rc;
+    ra.radius[k] = radii[k];
+    rmin = radii[k] < rmin ? radii[k] : rmin;
+  }
+  SN_REQUIRE(workspace_bytes >= sn_p2i_max_backward_multi_workspace_bytes(npoints, channels),
+             "sn_p2i_max_backward_multi: workspace too small");
+  hipStream_t s = sn::as_stream(stream);
+  const long px = (long)batch * channels * h * w;
+  unsigned *absmax = static_cast<unsigned *>(workspace);
+  long long *acc_pts = reinterpret_cast<long long *>(static_cast<char *>(workspace) + 256);
+  long long *acc_feat = acc_pts + (size_t)npoints * 2;
+  SN_HIP(hipMemsetAsync(workspace, 0, sn_p2i_max_backward_multi_workspace_bytes(npoints, channels), s));
+  p2i_absmax_kernel<<<512, 256, 0, s>>>(out_grad, px * nradii, feat,
+                                                           (long)npoints * channels, absmax);
+  const long per_image = (long)channels * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);  // tiles
+  const long blocks = (per_image + 3) / 4 * 8 * ((batch + 7) / 8);
+  SN_REQUIRE(blocks < (1L << 31), "sn_p2i_max_backward_multi: image too large");
+  p2i_max_bwd_accum_kernel<<<(int)blocks, 256, 0, s>>>(out_grad, out_ids, points, feat, absmax,
+                                                       background_grad, acc_pts, acc_feat, channels,
+                                                       batch, h, w, ra, nradii, rmin);
+  if (npoints > 0)
+    p2i_max_bwd_finish_kernel<<<lin_blocks((long)npoints * (2 + channels)), 256, 0, s>>>(
+        acc_pts, acc_feat, absmax, points_grad, feat_grad, (long)npoints * 2,
+        (long)npoints * channels, rmin);
+  return sn::launch_status("sn_p2i_max_backward_multi");
 }
 
 extern "C" int sn_p2i_sum_forward(const float *points, const float *feat, const int *batch_inds,

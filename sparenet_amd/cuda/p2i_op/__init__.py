@@ -96,6 +96,30 @@ class _Ext:
         return points_grad, feat_grad, bg_grad
 
     @staticmethod
+    def p2i_max_backward_multi_gpu(out_grad, out_point_ids, points, point_features, kernel_kind,
+                                   radii):
+        """out_grad / out_point_ids [len(radii), B, C, H, W] -> gradients summed over the radii
+        (sn_p2i_max_backward_multi: exact fixed-point accumulation, bit-reproducible)."""
+        n = points.size(0)
+        c = point_features.size(1)
+        nr, b, _, h, w = out_grad.shape
+        points_grad = torch.empty_like(points)
+        feat_grad = torch.empty_like(point_features)
+        bg_grad = torch.empty(out_grad.shape[1:], dtype=out_grad.dtype, device=out_grad.device)
+        host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
+        with torch.cuda.device_of(out_grad):
+            nbytes = _lib.lib().sn_p2i_max_backward_multi_workspace_bytes(n, c)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=out_grad.device)
+            code = _lib.lib().sn_p2i_max_backward_multi(
+                _lib.fptr(out_grad, "out_grad"), _lib.iptr(out_point_ids, "out_point_ids"),
+                _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
+                n, c, b, h, w, host_radii, nr, _lib.fptr(points_grad, "points_grad"),
+                _lib.fptr(feat_grad, "point_features_grad"), _lib.fptr(bg_grad, "background_grad"),
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(out_grad))
+        _lib.check(code, "sn_p2i_max_backward_multi")
+        return points_grad, feat_grad, bg_grad
+
+    @staticmethod
     def p2i_sum_forward_gpu(points, point_features, batch_inds, background, kernel_kind,
                             kernel_radius):
         if kernel_kind != 0:
@@ -169,16 +193,17 @@ class P2IMaxFunction(Function):
     @staticmethod
     def backward(ctx, out_grad):
         points, point_features, winner_ids, batch_inds = ctx.saved_tensors
-        g_points, g_feat, g_bg = ext.p2i_max_backward_gpu(
-            out_grad.contiguous(), winner_ids, *_c(points, point_features), *ctx.kind_radius,
-            batch_inds=batch_inds)
+        kind, radius = ctx.kind_radius
+        g_points, g_feat, g_bg = ext.p2i_max_backward_multi_gpu(
+            out_grad.contiguous().unsqueeze(0), winner_ids.unsqueeze(0),
+            *_c(points, point_features), kind, [radius])
         return g_points, g_feat, None, g_bg, None, None
 
 
 class P2IMaxMultiFunction(Function):
     """P2IMaxFunction for several kernel radii at once: returns [len(radii), B, C, H, W], slice
     r equal to P2IMaxFunction.apply(..., radii[r]).  The forward shares one binning and one
-    pixel walk between the radii; the backward is the per-radius backward, summed."""
+    pixel walk between the radii; the backward adds the radii's gradients in one pass."""
 
     @staticmethod
     def forward(ctx, points, point_features, batch_inds, background, kernel_kind, radii):
@@ -192,14 +217,8 @@ class P2IMaxMultiFunction(Function):
     def backward(ctx, out_grad):
         points, point_features, winner_ids, batch_inds = ctx.saved_tensors
         kind, radii = ctx.kind_radii
-        pts, feats = _c(points, point_features)
-        g_points = g_feat = g_bg = None
-        for r, radius in enumerate(radii):
-            gp, gf, gb = ext.p2i_max_backward_gpu(out_grad[r].contiguous(), winner_ids[r], pts,
-                                                  feats, kind, radius, batch_inds=batch_inds)
-            g_points = gp if g_points is None else g_points + gp
-            g_feat = gf if g_feat is None else g_feat + gf
-            g_bg = gb if g_bg is None else g_bg + gb
+        g_points, g_feat, g_bg = ext.p2i_max_backward_multi_gpu(
+            out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radii)
         return g_points, g_feat, None, g_bg, None, None
 
 

@@ -96,6 +96,13 @@ def test_hip_matches_functor_golden(golden_dir, dev):
         np.testing.assert_allclose(gp.cpu().numpy(), z["max_points_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
         np.testing.assert_allclose(gf.cpu().numpy(), z["max_feat_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
         assert np.array_equal(gb.cpu().numpy(), z["max_background_grad"]), f
+        # the pixel-centric backward with exact fixed-point accumulation (what autograd uses)
+        m1 = ext.p2i_max_backward_multi_gpu(t["out_grad"][None], t["max_ids"][None], t["points"], t["feat"], 0, [R])
+        m2 = ext.p2i_max_backward_multi_gpu(t["out_grad"][None], t["max_ids"][None], t["points"], t["feat"], 0, [R])
+        np.testing.assert_allclose(m1[0].cpu().numpy(), z["max_points_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
+        np.testing.assert_allclose(m1[1].cpu().numpy(), z["max_feat_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
+        assert np.array_equal(m1[2].cpu().numpy(), z["max_background_grad"]), f
+        assert all(torch.equal(a, b) for a, b in zip(m1, m2)), "integer accumulation is order independent"
         so = ext.p2i_sum_forward_gpu(t["points"], t["feat"], t["batch_inds"], t["background"], 0, R)
         np.testing.assert_allclose(so.cpu().numpy(), z["sum_out"], rtol=2e-5, atol=2e-6, err_msg=f)
         sgp, sgf = ext.p2i_sum_backward_gpu(t["out_grad"], t["points"], t["feat"], t["batch_inds"], 0, R)
