@@ -367,6 +367,12 @@ struct WaveTab {  // per-wave LDS: the 64 bidders it serves, and its hit queue
   int owner[64];
 };
 
+struct GroupAcc {  // per bidder group of a workgroup: the arrival-order merge of its segments
+  float best[64], better[64];
+  int bi[64], bi2[64];
+  int lock, arrived;
+};
+
 // level-1 threshold T' of one bidder: base = slack - |x|^2 is fixed, cm grows
 __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_max) {
   const float r = a_max - filter_thr(cm);
@@ -379,6 +385,12 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
     const float *__restrict__ bbox, const int *__restrict__ tperm, const int *__restrict__ list,
     const int *__restrict__ cnt, BidOut A, long long *__restrict__ stats) {
   __shared__ WaveTab tabs[kBidWaves];
+  __shared__ GroupAcc gacc[kBidWaves];
+  if (threadIdx.x < kBidWaves) {
+    gacc[threadIdx.x].lock = 0;
+    gacc[threadIdx.x].arrived = 0;
+  }
+  __syncthreads();
   // XCD-aware decode of the 1-D grid: workgroup `lin` runs on XCD lin % 8 and every cloud's
   // workgroups share that residue, so a cloud's streams + prices stay in ONE 4 MB L2
   // (4 clouds per XCD at B = 32) instead of cycling through every L2.
@@ -547,16 +559,34 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
       if (qcount > 0) batch(0, qcount);
       top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
     }
-    // merge the S partial results of a bidder group (segment 0's wave collects)
-    if (S > 1) {
-      __syncthreads();
-      if (seg == 0 && grp < ngroups)
-        for (int w = wave + 1; w < wave + S; ++w)
-          top2_merge(top, tabs[w].best[lane], tabs[w].better[lane], tabs[w].bi[lane],
-                     tabs[w].bi2[lane], geom);
-      __syncthreads();  // the tables are rewritten by the next work item
+    // Merge the S partial results of a bidder group in ARRIVAL order, without a barrier: a wave
+    // that is done takes the group's lock, folds its partial into the group accumulator (the
+    // first arrival just stores it) and leaves; the last arrival holds the complete top-2 and
+    // emits.  Early waves free their SIMD slots instead of waiting for the slowest segment.
+    bool emit = seg == 0;  // S == 1: every wave owns its group
+    if (S > 1 && grp < ngroups) {
+      GroupAcc &ga = gacc[gslot];
+      if (lane == 0)
+        while (atomicCAS(&ga.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const int arrived = ga.arrived;
+      if (arrived > 0)
+        top2_merge(top, ga.best[lane], ga.better[lane], ga.bi[lane], ga.bi2[lane], geom);
+      emit = arrived == S - 1;
+      if (!emit) {
+        ga.best[lane] = top.best;
+        ga.better[lane] = top.better;
+        ga.bi[lane] = top.best_i;
+        ga.bi2[lane] = top.better_i;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) {
+        ga.arrived = emit ? 0 : arrived + 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        atomicExch(&ga.lock, 0);
+      }
     }
-    if (seg == 0 && grp < ngroups) {
+    if (emit && grp < ngroups) {
       if (sp.nb == 1) {
         if (active) emit_bid(A, o, j, top, eps);
       } else {  // publish this workgroup's partial; emd_bid_finish_kernel merges the nb of them
@@ -564,6 +594,8 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
             make_float4(top.best, top.better, __int_as_float(top.best_i), __int_as_float(top.better_i));
       }
     }
+    // the accumulators and tables are reused by the block's next work item
+    if (q0 + G * gpb < ngroups * sp.nb) __syncthreads();
   }
 }
 

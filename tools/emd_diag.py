@@ -14,8 +14,11 @@ def run(it):
     emd_forward_raw(x, y, 0.005, it, st); torch.cuda.synchronize()
     return st.cpu()
 prev = run(0)
-print("iter: U_mean items cyc/item hitcyc/item enq_iters hits batches batchcyc/item rounds/batch")
-for it in (1, 2, 3, 7, 12, 20, 30, 50):
-    a = run(it - 1); b = run(it); dd = b - a; rec = dd[8:].view(-1, 8).sum(0).tolist(); d = dd[:8].tolist()
+print("iter: U_mean items setup scan finaldrain post (cycles/item)   kernel span (cycles, max end - min start)")
+for it in (1, 2, 7, 20, 30, 50):
+    a = run(it - 1); b = run(it); dd = b - a; recs = dd[8:].view(-1, 8); rec = recs.sum(0).tolist(); d = dd[:8].tolist()
     w = max(rec[5], 1)
-    print(f"{it:3d}: {d[0]/N/B:8.1f} {rec[5]:6d} {rec[0]/w:10.0f} {rec[1]/w:10.0f} {rec[2]/w:8.1f} {rec[3]/w:8.1f} {rec[4]/w:7.1f} {rec[6]/w:10.0f} {rec[7]/max(rec[4],1):6.2f}")
+    bb = b[8:].view(-1, 8); used = bb[:, 5] > 0
+    # stamps are absolute (assigned, not accumulated): use the last run's values
+    span = (bb[used][:, 7].max() - bb[used][:, 6].min()).item() if used.any() else 0
+    print(f"{it:3d}: {d[0]/N/B:8.1f} {rec[5]:6d} {rec[0]/w:9.0f} {rec[1]/w:9.0f} {rec[2]/w:9.0f} {rec[3]/w:9.0f}   span {span}")

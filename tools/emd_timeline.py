@@ -1,0 +1,24 @@
+"""Per-wave timeline of the last bid launch (needs the wall-clock diag build: AB_LIB=tools/ab/lib_diag.so)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
+from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
+dev = torch.device("cuda:0")
+B, N = 32, 16384
+g = torch.Generator().manual_seed(1234)
+x = torch.rand(B, N, 3, generator=g).to(dev); y = torch.rand(B, N, 3, generator=g).to(dev)
+for it in (2, 20, 50):
+    st = torch.zeros(8 + 1024 * 16 * 4, dtype=torch.int64, device=dev)
+    emd_forward_raw(x, y, 0.005, it, st); torch.cuda.synchronize()
+    r = st[8:].view(-1, 4).cpu().numpy().astype(np.float64)
+    last = r[:, 0] >= r[:, 0].max() - 100 * 2000      # records stamped in the last 2 ms
+    r = r[last]
+    t0 = r[:, 0].min()
+    start = (r[:, 0] - t0) / 100; setup = r[:, 1] / 100; scan = r[:, 2] / 100; post = r[:, 3] / 100
+    end = start + setup + scan + post
+    pc = lambda a: " ".join(f"{np.percentile(a, q):7.1f}" for q in (10, 50, 90, 99, 100))
+    print(f"iter {it}: waves {len(r)}  (us, p10 p50 p90 p99 max)")
+    print("   start", pc(start)); print("   setup", pc(setup)); print("   scan ", pc(scan)); print("   post ", pc(post)); print("   end  ", pc(end))
