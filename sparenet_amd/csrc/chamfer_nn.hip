@@ -1,0 +1,373 @@
+// chamfer_nn.hip -- Chamfer forward as a spatially pruned nearest-neighbour search (gfx950).
+//
+// Same contract as chamfer.hip (reference cuda/chamfer_distance/chamfer_distance.cu:7-137,
+// CPU statement chamfer_distance.cpp:57-112):
+//   dist[b,j] = min_k d(j,k),  d = (dx*dx + dy*dy) + dz*dz, dx = t.x - q.x, separately rounded;
+//   idx[b,j]  = LOWEST k attaining the minimum.
+// chamfer.hip evaluates all n*m pairs (VALU bound, 2.7 ms at B=32, n=m=16384).  Here both
+// clouds are put in Morton order (cloud_sort.hpp) and the search is filtered twice:
+//   * superblock level: 64 consecutive sorted targets carry a bounding box; a wave serves 64
+//     consecutive sorted QUERIES (spatial neighbours), keeps their bounding box and the largest
+//     current best distance R2max, and skips every superblock whose box is farther than that.
+//     The test runs for 64 superblocks at a time, lane = superblock.
+//   * pair level, on the matrix cores: u = |t|^2 - 2 t.q for 16 targets x 16 queries is one
+//     v_mfma_f32_16x16x4_f32 (exact fp32); a pair can only matter if u <= best_q - |q|^2 + slack.
+//     The slack 2^-18 (max|t|^2 + |q|^2) covers the fmaf chain's rounding, the stored |t|^2 and
+//     |q|^2 and the evaluation of the threshold; (1 + 2^-20) covers the rounding of the exact d.
+//   * survivors go to a per-wave LDS queue and are evaluated 64 at a time with the reference's
+//     expression; the result meets the query through a 64-bit LDS atomicMin on
+//     (bits of d) << 32 | k.  d >= 0, so its bit pattern orders like the value: the minimum key
+//     is the minimum distance and, among equal distances, the lowest k -- the reference's rule,
+//     independent of the visiting order.
+// Every query starts from the best of 8 sorted targets around its own Morton cell, so the ball
+// it still has to search is already ~1.5 nearest-neighbour distances wide.
+#include "cloud_sort.hpp"
+#include "common.hpp"
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+struct NnSide {       // one cloud in Morton order
+  const float *xyz;   // [B, n, 3] as given
+  int n, nsb;         // points, superblocks of 64
+  int *perm;          // [B, n] sorted position -> index
+  int *hist;          // [B, 4096] cell END offsets after the scatter
+  float *bbox;        // [B, 6]
+  f4 *sorted4;        // [B, nsb*64] {x, y, z, index bits}; padding: index -1
+  f4 *mstream;        // [B, nsb, 64] MFMA A operand, see emd.hip
+  float *sbbox;       // [B, nsb, 8] lo xyz, hi xyz, 0, 0
+};
+
+__device__ __forceinline__ float exact_d(float tx, float ty, float tz, float qx, float qy, float qz) {
+#pragma clang fp contract(off)
+  const float dx = tx - qx, dy = ty - qy, dz = tz - qz;
+  const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  return (xx + yy) + zz;
+}
+
+// one wave per superblock: sorted coordinates, MFMA operand stream, bounding box
+__global__ __launch_bounds__(256) void nn_prepare_kernel(int B, NnSide S) {
+#pragma clang fp contract(off)
+  const long sb_all = (long)B * S.nsb;
+  const int lane = threadIdx.x & 63;
+  for (long sb = (long)blockIdx.x * 4 + (threadIdx.x >> 6); sb < sb_all; sb += (long)gridDim.x * 4) {
+    const long b = sb / S.nsb;
+    const int p = (int)(sb - b * S.nsb) * 64 + lane;  // sorted position inside the cloud
+    const bool valid = p < S.n;
+    const int k = valid ? S.perm[b * S.n + p] : -1;
+    const float *t = S.xyz + (b * S.n + (valid ? k : 0)) * 3;
+    const float x = valid ? t[0] : 0.f, y = valid ? t[1] : 0.f, z = valid ? t[2] : 0.f;
+    S.sorted4[sb * 64 + lane] = f4{x, y, z, __int_as_float(k)};
+    // padding never passes the filter: |t|^2 = 3e38
+    const float tt = valid ? (x * x + y * y) + z * z : 3.0e38f;
+    float *m = reinterpret_cast<float *>(S.mstream + sb * 64);
+    const int q = (lane >> 4) & 3, c = lane & 15;
+    m[(0 * 16 + c) * 4 + q] = -2.f * x;
+    m[(1 * 16 + c) * 4 + q] = -2.f * y;
+    m[(2 * 16 + c) * 4 + q] = -2.f * z;
+    m[(3 * 16 + c) * 4 + q] = tt;
+    float lo[3] = {valid ? x : 3e38f, valid ? y : 3e38f, valid ? z : 3e38f};
+    float hi[3] = {valid ? x : -3e38f, valid ? y : -3e38f, valid ? z : -3e38f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      for (int s = 1; s < 64; s <<= 1) {
+        lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], s));
+        hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], s));
+      }
+    if (lane < 8) {
+      const float v = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2] : lane == 3 ? hi[0]
+                    : lane == 4 ? hi[1] : lane == 5 ? hi[2] : 0.f;
+      S.sbbox[sb * 8 + lane] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ float min16(const f4 a, const f4 b, const f4 c, const f4 d) {
+  const float m0 = __builtin_fminf(__builtin_fminf(a.x, a.y), a.z);
+  const float m1 = __builtin_fminf(__builtin_fminf(a.w, b.x), b.y);
+  const float m2 = __builtin_fminf(__builtin_fminf(b.z, b.w), c.x);
+  const float m3 = __builtin_fminf(__builtin_fminf(c.y, c.z), c.w);
+  const float m4 = __builtin_fminf(__builtin_fminf(d.x, d.y), d.z);
+  const float m5 = __builtin_fminf(__builtin_fminf(m0, m1), d.w);
+  return __builtin_fminf(__builtin_fminf(m2, m3), __builtin_fminf(m4, m5));
+}
+
+__device__ __forceinline__ unsigned hits4(const f4 d, float thr, int shift) {
+  return ((d.x <= thr ? 1u : 0u) | (d.y <= thr ? 2u : 0u) | (d.z <= thr ? 4u : 0u) |
+          (d.w <= thr ? 8u : 0u)) << shift;
+}
+
+constexpr int kQueue = 128;
+
+struct NnTab {  // per-wave LDS
+  float x[64], y[64], z[64];
+  unsigned long long key[64];  // (bits of the best d) << 32 | its lowest k
+  unsigned queue[kQueue];      // sorted target position | query lane << 26
+};
+
+// squared distance between two boxes, rounded down a little
+__device__ __forceinline__ float box_gap2(const float *qlo, const float *qhi, float lx, float ly,
+                                          float lz, float hx, float hy, float hz) {
+  const float gx = __builtin_fmaxf(__builtin_fmaxf(lx - qhi[0], qlo[0] - hx), 0.f);
+  const float gy = __builtin_fmaxf(__builtin_fmaxf(ly - qhi[1], qlo[1] - hy), 0.f);
+  const float gz = __builtin_fmaxf(__builtin_fmaxf(lz - qhi[2], qlo[2] - hz), 0.f);
+  return ((gx * gx + gy * gy) + gz * gz) * 0.9999f;
+}
+
+__global__ __launch_bounds__(256) void nn_search_kernel(int B, NnSide S1, NnSide S2,
+                                                        float *__restrict__ dist1,
+                                                        int *__restrict__ idx1,
+                                                        float *__restrict__ dist2,
+                                                        int *__restrict__ idx2, int bpc) {
+  __shared__ NnTab tabs[4];
+  // XCD-aware: the 2B (direction, cloud) searches are dealt to the XCDs, all workgroups of one
+  // search share block id % 8 so that its target streams stay in one L2
+  const int lin = blockIdx.x, xcd = lin & 7, rr = lin >> 3;
+  const int cidx = (rr / bpc) * 8 + xcd;
+  if (cidx >= 2 * B) return;
+  const int dir = cidx / B, b = cidx - dir * B;
+  const NnSide Q = dir == 0 ? S1 : S2;  // queries
+  const NnSide T = dir == 0 ? S2 : S1;  // targets
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int grp = (rr % bpc) * 4 + wave;  // group of 64 sorted queries
+  if (grp >= Q.nsb) return;               // whole wave; no workgroup barrier below
+  const int row = lane >> 4, col = lane & 15;
+  NnTab &W = tabs[wave];
+  const f4 *__restrict__ t4 = T.sorted4 + (size_t)b * T.nsb * 64;
+
+  // ---- this wave's queries, their seeds -------------------------------------------------
+  const f4 q = Q.sorted4[((size_t)b * Q.nsb + grp) * 64 + lane];
+  const int qk = __float_as_int(q.w);
+  const bool active = qk >= 0;
+  unsigned long long key = ~0ull;
+  if (active) {
+    const float *box = T.bbox + b * 6;
+    unsigned cq[3];
+    const float v[3] = {q.x, q.y, q.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float ext = box[3 + a] - box[a];
+      const float f = ext > 0.f ? (v[a] - box[a]) * (15.999f / ext) : 0.f;
+      cq[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
+    }
+    const int c = (int)morton3_4bit(cq[0], cq[1], cq[2]);
+    const int start = c > 0 ? T.hist[b * kSortCells + c - 1] : 0;  // END of the previous cell
+    int lo = start - 2;
+    lo = lo < 0 ? 0 : (lo > T.n - 8 ? T.n - 8 : lo);
+    lo = lo < 0 ? 0 : lo;
+    const int cnt = T.n < 8 ? T.n : 8;
+    for (int p = lo; p < lo + cnt; ++p) {
+      const f4 t = t4[p];
+      const float d = exact_d(t.x, t.y, t.z, q.x, q.y, q.z);
+      const unsigned long long kk = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
+      key = kk < key ? kk : key;
+    }
+  }
+  W.x[lane] = q.x;
+  W.y[lane] = q.y;
+  W.z[lane] = q.z;
+  W.key[lane] = key;
+  float qlo[3] = {active ? q.x : 3e38f, active ? q.y : 3e38f, active ? q.z : 3e38f};
+  float qhi[3] = {active ? q.x : -3e38f, active ? q.y : -3e38f, active ? q.z : -3e38f};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    for (int s = 1; s < 64; s <<= 1) {
+      qlo[a] = __builtin_fminf(qlo[a], __shfl_xor(qlo[a], s));
+      qhi[a] = __builtin_fmaxf(qhi[a], __shfl_xor(qhi[a], s));
+    }
+  float tmax = 0.f;  // upper bound of every stored |t|^2: the far corner of the targets' box
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float l0 = T.bbox[b * 6 + a], h0 = T.bbox[b * 6 + 3 + a];
+    tmax += __builtin_fmaxf(l0 * l0, h0 * h0);
+  }
+  tmax *= 1.0001f;
+
+  // the four queries this lane filters for (column col of query group g), MFMA B operand
+  float thr[4], base[4], bop[4];
+  bool live[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma clang fp contract(off)
+    const int c = 16 * g + col;
+    const float x = W.x[c], y = W.y[c], z = W.z[c];
+    const float xx = (x * x + y * y) + z * z;
+    base[g] = 3.814697265625e-06f * (tmax + xx) - xx;
+    live[g] = W.key[c] != ~0ull;
+    bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
+  }
+  float r2max = 0.f;  // wave-uniform: largest current best of the wave's queries
+  auto refresh = [&]() {
+    const float mine = active ? __uint_as_float((unsigned)(W.key[lane] >> 32)) : 0.f;
+    float m = mine;
+    for (int s = 1; s < 64; s <<= 1) m = __builtin_fmaxf(m, __shfl_xor(m, s));
+    r2max = m;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float best = __uint_as_float((unsigned)(W.key[16 * g + col] >> 32));
+      thr[g] = live[g] ? __builtin_fmaf(best, 1.00000095367431640625f, base[g]) : -3.0e38f;
+    }
+  };
+  refresh();
+
+  int qcount = 0;  // wave-uniform
+  auto batch = [&](int first, int count) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < count) {
+      const unsigned e = W.queue[first + lane];
+      const int c = (int)(e >> 26);
+      const f4 t = t4[e & 0x3ffffffu];
+      const float d = exact_d(t.x, t.y, t.z, W.x[c], W.y[c], W.z[c]);
+      atomicMin(&W.key[c], ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  };
+
+  const f4 *__restrict__ ms = T.mstream + (size_t)b * T.nsb * 64;
+  const float *__restrict__ sbb = T.sbbox + (size_t)b * T.nsb * 8;
+  for (int sb0 = 0; sb0 < T.nsb; sb0 += 64) {
+    // which of these 64 superblocks can hold a pair that still matters? (lane = superblock)
+    const int sbl = sb0 + lane;
+    bool visit = false;
+    if (sbl < T.nsb) {
+      const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8);
+      const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8 + 4);
+      visit = box_gap2(qlo, qhi, lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y) <= r2max;
+    }
+    unsigned long long todo = __ballot(visit);
+    while (todo) {
+      const int sb = sb0 + __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const f4 a = ms[(size_t)sb * 64 + lane];
+      bool drained = false;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f4 zero = {0.f, 0.f, 0.f, 0.f};
+        const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
+        const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
+        const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
+        const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+        if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
+          // bit 4 q + r  <->  sorted target position 64 sb + 16 q + 4 row + r
+          unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
+                        hits4(d3, thr[g], 12);
+          while (__any(hm != 0)) {
+            const bool has = hm != 0;
+            const int i = has ? __builtin_ctz(hm) : 0;
+            hm &= hm - 1;
+            const unsigned long long bal = __ballot(has);
+            const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
+                                         (unsigned)(bal >> 32),
+                                         __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (has)
+              W.queue[pos] = (unsigned)(sb * 64 + 16 * (i >> 2) + 4 * row + (i & 3)) |
+                             ((unsigned)(16 * g + col) << 26);
+            qcount += __popcll(bal);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            while (qcount >= 64) {
+              qcount -= 64;
+              batch(qcount, 64);
+              drained = true;
+            }
+          }
+        }
+      }
+      if (drained) {  // tighter bests: fewer superblocks of this chunk remain worth a visit
+        refresh();
+        if (todo) {
+          bool still = false;
+          if (sbl < T.nsb && ((todo >> lane) & 1ull)) {
+            const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8);
+            const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8 + 4);
+            still = box_gap2(qlo, qhi, lo4.x, lo4.y, lo4.z, lo4.w, hi4.x, hi4.y) <= r2max;
+          }
+          todo = __ballot(still);
+        }
+      }
+    }
+    if (qcount > 0) {  // keep the bests current between chunks
+      batch(0, qcount);
+      qcount = 0;
+      refresh();
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (active) {
+    const unsigned long long kf = W.key[lane];
+    float *dist = dir == 0 ? dist1 : dist2;
+    int *idx = dir == 0 ? idx1 : idx2;
+    dist[(size_t)b * Q.n + qk] = __uint_as_float((unsigned)(kf >> 32));
+    idx[(size_t)b * Q.n + qk] = (int)(unsigned)kf;
+  }
+}
+
+struct SideBytes {
+  size_t perm, hist, bbox, sorted4, mstream, sbbox, total;
+};
+SideBytes side_bytes(int b, int n) {
+  const size_t nsb = (size_t)sn::ceil_div(n, 64);
+  SideBytes s;
+  s.perm = sn::align_up((size_t)b * n * 4, 256);
+  s.hist = (size_t)b * kSortCells * 4;
+  s.bbox = sn::align_up((size_t)b * 24, 256);
+  s.sorted4 = (size_t)b * nsb * 64 * 16;
+  s.mstream = (size_t)b * nsb * 64 * 16;
+  s.sbbox = (size_t)b * nsb * 32;
+  s.total = s.perm + s.hist + s.bbox + s.sorted4 + s.mstream + s.sbbox;
+  return s;
+}
+
+NnSide carve_side(char *&p, const float *xyz, int b, int n) {
+  const SideBytes sz = side_bytes(b, n);
+  NnSide s;
+  s.xyz = xyz;
+  s.n = n;
+  s.nsb = sn::ceil_div(n, 64);
+  s.perm = reinterpret_cast<int *>(p); p += sz.perm;
+  s.hist = reinterpret_cast<int *>(p); p += sz.hist;
+  s.bbox = reinterpret_cast<float *>(p); p += sz.bbox;
+  s.sorted4 = reinterpret_cast<f4 *>(p); p += sz.sorted4;
+  s.mstream = reinterpret_cast<f4 *>(p); p += sz.mstream;
+  s.sbbox = reinterpret_cast<float *>(p); p += sz.sbbox;
+  return s;
+}
+
+}  // namespace
+
+extern "C" size_t sn_chamfer_workspace_bytes(int b, int n, int m) {
+  if (b < 1 || n < 1 || m < 1) return 0;
+  const int big = n > m ? n : m;
+  return side_bytes(b, n).total + side_bytes(b, m).total + sn::align_up((size_t)b * big * 4, 256);
+}
+
+extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, int b, int n, int m,
+                                         float *dist1, int *idx1, float *dist2, int *idx2,
+                                         void *workspace, size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(xyz1 && xyz2 && dist1 && idx1 && dist2 && idx2 && workspace,
+             "sn_chamfer_forward_sorted: null pointer");
+  SN_REQUIRE(b >= 1 && n >= 1 && m >= 1, "sn_chamfer_forward_sorted: need b,n,m >= 1 (got %d,%d,%d)", b, n, m);
+  SN_REQUIRE((long)b * n < (1L << 26) && (long)b * m < (1L << 26) && n < (1 << 26) && m < (1 << 26),
+             "sn_chamfer_forward_sorted: too large");
+  SN_REQUIRE(workspace_bytes >= sn_chamfer_workspace_bytes(b, n, m),
+             "sn_chamfer_forward_sorted: workspace too small (%zu < %zu)", workspace_bytes,
+             sn_chamfer_workspace_bytes(b, n, m));
+  hipStream_t s = sn::as_stream(stream);
+  char *p = static_cast<char *>(workspace);
+  NnSide s1 = carve_side(p, xyz1, b, n), s2 = carve_side(p, xyz2, b, m);
+  int *cell_of = reinterpret_cast<int *>(p);  // sort scratch, shared by the two clouds
+  if (sn::prof_enabled()) sn::prof_begin("chamfer_fwd", s);
+  for (NnSide *side : {&s1, &s2}) {
+    const long total = (long)b * side->n;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    cloud_sort_count_kernel<<<b, 1024, 0, s>>>(side->n, side->xyz, side->bbox, side->hist, cell_of);
+    cloud_sort_scatter_kernel<<<blocks, 256, 0, s>>>(side->n, cell_of, side->hist, side->perm, total);
+    const long sbs = (long)b * side->nsb;
+    nn_prepare_kernel<<<(int)((sbs + 3) / 4 < 4096 ? (sbs + 3) / 4 : 4096), 256, 0, s>>>(b, *side);
+  }
+  const int bpc = sn::ceil_div((s1.nsb > s2.nsb ? s1.nsb : s2.nsb), 4);  // workgroups per search
+  const int grid = 8 * sn::ceil_div(2 * b, 8) * bpc;
+  nn_search_kernel<<<grid, 256, 0, s>>>(b, s1, s2, dist1, idx1, dist2, idx2, bpc);
+  if (sn::prof_enabled()) sn::prof_end("chamfer_fwd", s);
+  return sn::launch_status("sn_chamfer_forward_sorted");
+}

@@ -15,16 +15,37 @@ class _CdBinding:
     """Stand-in for the reference's JIT-built `cd` extension module
     (chamfer_distance.cpp:182-188): caller-allocated outputs, GPU entry points."""
 
+    # below this many pairs per cloud the all-pairs kernel wins over sort + pruned search
+    SORTED_MIN_PAIRS = 1 << 22
+
     @staticmethod
     def forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2):
         b, n, _ = xyz1.shape
         m = xyz2.shape[1]
+        if n * m >= _CdBinding.SORTED_MIN_PAIRS and b * max(n, m) < (1 << 26):
+            return _CdBinding.forward_sorted_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
         with torch.cuda.device_of(xyz1):
             code = _lib.lib().sn_chamfer_forward(
                 _lib.fptr(xyz1, "xyz1"), _lib.fptr(xyz2, "xyz2"), b, n, m,
                 _lib.fptr(dist1, "dist1"), _lib.iptr(idx1, "idx1"),
                 _lib.fptr(dist2, "dist2"), _lib.iptr(idx2, "idx2"), _lib.stream_of(xyz1))
         _lib.check(code, "sn_chamfer_forward")
+
+    @staticmethod
+    def forward_sorted_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2):
+        """sn_chamfer_forward_sorted: identical outputs through a spatially pruned search."""
+        import ctypes
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        with torch.cuda.device_of(xyz1):
+            nbytes = _lib.lib().sn_chamfer_workspace_bytes(b, n, m)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz1.device)
+            code = _lib.lib().sn_chamfer_forward_sorted(
+                _lib.fptr(xyz1, "xyz1"), _lib.fptr(xyz2, "xyz2"), b, n, m,
+                _lib.fptr(dist1, "dist1"), _lib.iptr(idx1, "idx1"),
+                _lib.fptr(dist2, "dist2"), _lib.iptr(idx2, "idx2"),
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(xyz1))
+        _lib.check(code, "sn_chamfer_forward_sorted")
 
     @staticmethod
     def backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
