@@ -36,9 +36,6 @@
 namespace {
 
 // split constants (tools build A/B variants with -D)
-#ifndef SN_EMD_MAXSEG
-#define SN_EMD_MAXSEG 64
-#endif
 #ifndef SN_EMD_G
 #define SN_EMD_G 32
 #endif
@@ -181,7 +178,12 @@ struct EmdWs {
   int *cell_of;  // [B, n] sort scratch
   int *hist;     // [B, 4096] cell offsets of the sorted targets
   float *bbox;   // [B, 6] bounding box of the targets (also bounds |t|^2 for the filter slack)
-  float *partial;  // [B][16][4][64] float4
+  float *sbbox;  // [B, n/64, 8] bounding box of every 64-target superblock of the stream
+  int *perm1;    // [B, n] Morton rank -> bidder index
+  int *rank1;    // [B, n] bidder index -> Morton rank
+  int *flags;    // [B, n] by rank: unassigned after this iteration (next list = flagged ranks in order)
+  int *hist1;    // [B, 4096] sort scratch of the bidders
+  float *bbox1;  // [B, 6]
 };
 
 __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
@@ -197,7 +199,9 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.max_idx[e] = 0;
     ws.bid[e] = -1;   // no previous favourites yet (filter seeding)
     ws.bid2[e] = -1;
-    ws.list[0][e] = (int)(e % n);
+    ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
+    ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
+    ws.flags[e] = 0;
     ws.tgt4[e] = f4{xyz2[e * 3 + 0], xyz2[e * 3 + 1], xyz2[e * 3 + 2], filter_target(0.f)};
     {  // stream position p of this cloud holds target tperm[p]
       const long bb = e / n;
@@ -216,6 +220,27 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
       ws.cnt[0][e] = n;
       ws.cnt[1][e] = 0;
     }
+  }
+}
+
+// bounding box of every superblock (64 consecutive targets of the Morton-ordered stream)
+__global__ __launch_bounds__(256) void emd_sbbox_kernel(int B, int n, const float *__restrict__ xyz2,
+                                                        EmdWs ws) {
+  const long sb_all = (long)B * (n >> 6);
+  const int lane = threadIdx.x & 63;
+  for (long sb = (long)blockIdx.x * 4 + (threadIdx.x >> 6); sb < sb_all; sb += (long)gridDim.x * 4) {
+    const long bb = sb / (n >> 6);
+    const float *t = xyz2 + (bb * n + ws.tperm[sb * 64 + lane]) * 3;
+    float lo[3] = {t[0], t[1], t[2]}, hi[3] = {t[0], t[1], t[2]};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      for (int m = 1; m < 64; m <<= 1) {
+        lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], m));
+        hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], m));
+      }
+    if (lane < 8)
+      ws.sbbox[sb * 8 + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2]
+                              : lane == 3 ? hi[0] : lane == 4 ? hi[1] : lane == 5 ? hi[2] : 0.f;
   }
 }
 
@@ -274,31 +299,18 @@ struct BidOut {
   int *bid, *bid2;
   float *bid_inc, *max_inc;
   int *max_idx;
-  float4 *partial;  // [B][kMaxSplitGroups][kMaxSplit][64] cross-workgroup partial top-2's
 };
 
 constexpr int kBidWaves = 16;
 constexpr int kBidThreads = kBidWaves * 64;
-constexpr int kMaxSegments = SN_EMD_MAXSEG;                          // waves per bidder group, at most
-constexpr int kMaxSplit = kMaxSegments / kBidWaves;       // workgroups per bidder group, at most
-constexpr int kMaxSplitGroups = 16;                       // groups per cloud that may be split
 
-// How a cloud's G*16 waves are spread over its ngroups groups of 64 bidders:
-// S_total = 2^k <= 64 waves per group (each scanning n/S_total targets); up to 16 of them live
-// in one workgroup (LDS merge), the rest in sibling workgroups (merge in emd_bid_finish_kernel).
-struct BidSplit {
-  int s_total, s_block, nb;
-};
-__host__ __device__ inline BidSplit bid_split(int ngroups, int G, int n) {
+// S = 2^k <= 16 waves of one workgroup share a group of 64 bidders (superblock sb belongs to wave
+// sb mod S); chosen on the device from the unassigned count so that the fixed grid of G
+// workgroups per cloud stays busy when few bidders are left.
+__host__ __device__ inline int bid_split(int ngroups, int G) {
   int s = 1;
-  // a segment is a whole number of 64-target superblocks (n is a multiple of 1024)
-  while (s < kMaxSegments && s * 2 * ngroups <= G * kBidWaves && (n / (s * 2)) % 64 == 0) s *= 2;
-  if (s > kBidWaves && ngroups > kMaxSplitGroups) s = kBidWaves;
-  BidSplit r;
-  r.s_total = s;
-  r.s_block = s < kBidWaves ? s : kBidWaves;
-  r.nb = s / r.s_block;
-  return r;
+  while (s < kBidWaves && s * 2 * ngroups <= G * kBidWaves) s *= 2;
+  return s;
 }
 
 __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const Top2 &top,
@@ -382,8 +394,9 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
 __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
     int B, int G, int n, float eps, float price_floor, const float *__restrict__ xyz1,
     const float *__restrict__ price, const f4 *__restrict__ tgt4, const f4 *__restrict__ mstream,
-    const float *__restrict__ bbox, const int *__restrict__ tperm, const int *__restrict__ list,
-    const int *__restrict__ cnt, BidOut A, long long *__restrict__ stats) {
+    const float *__restrict__ bbox, const float *__restrict__ sbbox, const int *__restrict__ tperm,
+    const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
+    long long *__restrict__ stats) {
   __shared__ WaveTab tabs[kBidWaves];
   __shared__ GroupAcc gacc[kBidWaves];
   if (threadIdx.x < kBidWaves) {
@@ -417,12 +430,11 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
   WaveTab &T = tabs[wave];
 
   const int ngroups = (U + 63) >> 6;
-  const BidSplit sp = bid_split(ngroups, G, n);
-  const int S = sp.s_block;        // segments (waves) of one group inside this workgroup
-  const int gpb = kBidWaves / S;   // bidder groups per workgroup (1 when the group is split)
-  const int seg = wave & (S - 1);  // this wave's segment within the workgroup
+  const int S = bid_split(ngroups, G);  // waves per bidder group
+  const int gpb = kBidWaves / S;        // bidder groups per workgroup
+  const int seg = wave & (S - 1);       // this wave takes superblocks sb with sb mod S == seg
   const int gslot = wave / S;
-  const int seg_len = n / sp.s_total;  // a multiple of 64
+  const int nsb = n >> 6;
 
   // reference partition, only needed to order exact ties (emd_cuda.cu:108-109,136)
   const int block_cnt = n / 1024;
@@ -437,20 +449,34 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
   }
   tmax *= 1.0001f;
 
-  // work items: (group, part) with part < nb; a workgroup takes gpb consecutive groups (nb == 1)
-  // or one (group, part) (nb > 1)
-  for (int q0 = bx * gpb; q0 < ngroups * sp.nb; q0 += G * gpb) {  // uniform per block
-    const int grp = sp.nb > 1 ? q0 / sp.nb : q0 + gslot;
-    const int part = sp.nb > 1 ? q0 % sp.nb : 0;
-    const int k_begin = (part * S + seg) * seg_len, k_end = k_begin + seg_len;
+  // a workgroup takes gpb consecutive bidder groups per pass
+  for (int q0 = bx * gpb; q0 < ngroups; q0 += G * gpb) {  // uniform per block
+    const int grp = q0 + gslot;
     const int u = grp * 64 + lane;
     const bool active = grp < ngroups && u < U;
     const int j = lst[active ? u : 0];
     Top2 top = {-1e9f, -1e9f, -1, -1};
 
     if (grp < ngroups) {  // wave-uniform
+      float blo[3], bhi[3];  // wave-uniform bounding box of the wave's bidders
+      float own_slack2;      // 2 x the filter slack of this lane's own bidder
       {
         const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
+        {
+#pragma clang fp contract(off)
+          const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
+          own_slack2 = 2.f * 3.814697265625e-06f * (tmax + xx);
+          const float v[3] = {x1, y1, z1};
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            blo[a] = active ? v[a] : 3.0e38f;
+            bhi[a] = active ? v[a] : -3.0e38f;
+            for (int m = 1; m < 64; m <<= 1) {
+              blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], m));
+              bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], m));
+            }
+          }
+        }
         // seed the filter with the bidder's previous two favourites under today's prices:
         // both are real targets, so the final `better` is at least the smaller of the two.
         float cm = -1e9f;
@@ -512,47 +538,75 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         asm volatile("" ::: "memory");
       };
 
-      const f4 *ms = mstream + ((size_t)b * (n >> 6) + (k_begin >> 6)) * 64 + lane;
-      f4 a_next = ms[0];
-      for (int kb = k_begin; kb < k_end; kb += 64) {
-        const f4 a = a_next;
-        ms += (kb + 64 < k_end) ? 64 : 0;
-        a_next = ms[0];  // the next superblock is in flight during this one
+      // Superblock pruning.  A pair passes the coarse filter only if |t - x_j|^2 (up to the slack)
+      // is below T'_j + |x_j|^2; r2max is the largest such reach over the wave's bidders, and a
+      // superblock whose bounding box is farther than that from the bidders' box cannot produce a
+      // single hit -- skipping it changes nothing.  64 superblocks are tested at a time, lane =
+      // superblock; the reach shrinks as the thresholds tighten.
+      float r2max;
+      auto refresh_reach = [&]() {
+        float v = active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f;
+        for (int m = 1; m < 64; m <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m));
+        r2max = v > 0.f ? v * 1.0001f : v;
+      };
+      refresh_reach();
+      const f4 *ms = mstream + (size_t)b * nsb * 64 + lane;
+      const float *sbb = sbbox + (size_t)b * nsb * 8;
+      auto worth = [&](int sbl) {
+        const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8);
+        const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8 + 4);
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(lo4.x - bhi[0], blo[0] - lo4.w), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(lo4.y - bhi[1], blo[1] - hi4.x), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(lo4.z - bhi[2], blo[2] - hi4.y), 0.f);
+        return ((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2max;
+      };
+      for (int sb0 = 0; sb0 < nsb; sb0 += 64) {
+        const int sbl = sb0 + lane;
+        const bool mine = sbl < nsb && (sbl & (S - 1)) == seg;
+        unsigned long long todo = __ballot(mine && worth(sbl));
+        while (todo) {
+          const int sb = sb0 + __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const int kb = sb * 64;
+          const f4 a = ms[(size_t)sb * 64];
+          bool drained = false;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
-          const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
-          const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
-          const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
-          if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
-            // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
-            unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
-                          hits4(d3, thr[g], 12);
-            bool drained = false;
-            while (__any(hm != 0)) {
-              const bool has = hm != 0;
-              const int i = has ? __builtin_ctz(hm) : 0;
-              hm &= hm - 1;
-              const unsigned long long bal = __ballot(has);
-              const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
-                                           (unsigned)(bal >> 32),
-                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-              if (has)
-                T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
-                               ((unsigned)(16 * g + col) << 20);
-              qcount += __popcll(bal);
-              while (qcount >= 64) {
-                qcount -= 64;
-                batch(qcount, 64);
-                drained = true;
+          for (int g = 0; g < 4; ++g) {
+            const f4 zero = {0.f, 0.f, 0.f, 0.f};
+            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
+            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
+            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
+            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+            if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
+              // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
+              unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
+                            hits4(d3, thr[g], 12);
+              while (__any(hm != 0)) {
+                const bool has = hm != 0;
+                const int i = has ? __builtin_ctz(hm) : 0;
+                hm &= hm - 1;
+                const unsigned long long bal = __ballot(has);
+                const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
+                                             (unsigned)(bal >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (has)
+                  T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
+                                 ((unsigned)(16 * g + col) << 20);
+                qcount += __popcll(bal);
+                while (qcount >= 64) {
+                  qcount -= 64;
+                  batch(qcount, 64);
+                  drained = true;
+                }
               }
             }
-            if (drained) {
+          }
+          if (drained) {  // tighter thresholds: less reach, fewer superblocks left to visit
 #pragma unroll
-              for (int gg = 0; gg < 4; ++gg)
-                thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
-            }
+            for (int gg = 0; gg < 4; ++gg)
+              thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
+            refresh_reach();
+            if (todo) todo = __ballot(((todo >> lane) & 1ull) && worth(sbl));
           }
         }
       }
@@ -586,51 +640,18 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         atomicExch(&ga.lock, 0);
       }
     }
-    if (emit && grp < ngroups) {
-      if (sp.nb == 1) {
-        if (active) emit_bid(A, o, j, top, eps);
-      } else {  // publish this workgroup's partial; emd_bid_finish_kernel merges the nb of them
-        A.partial[(((size_t)b * kMaxSplitGroups + grp) * kMaxSplit + part) * 64 + lane] =
-            make_float4(top.best, top.better, __int_as_float(top.best_i), __int_as_float(top.better_i));
-      }
-    }
+    if (emit && active) emit_bid(A, o, j, top, eps);
     // the accumulators and tables are reused by the block's next work item
-    if (q0 + G * gpb < ngroups * sp.nb) __syncthreads();
+    if (q0 + G * gpb < ngroups) __syncthreads();
   }
-}
-
-// merges the partial top-2's of bidder groups that were split over several workgroups
-__global__ __launch_bounds__(kBidThreads) void emd_bid_finish_kernel(
-    int G, int n, float eps, const int *__restrict__ list, const int *__restrict__ cnt, BidOut A) {
-  const int b = blockIdx.x;
-  const int U = cnt[b];
-  if (U == 0) return;
-  const int ngroups = (U + 63) >> 6;
-  const BidSplit sp = bid_split(ngroups, G, n);
-  if (sp.nb == 1) return;
-  const int grp = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int u = grp * 64 + lane;
-  if (grp >= ngroups || u >= U) return;
-  const size_t o = (size_t)b * n;
-  const int block_cnt = n / 1024;
-  const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
-  const float4 *pp = A.partial + ((size_t)b * kMaxSplitGroups + grp) * kMaxSplit * 64 + lane;
-  const float4 p0 = pp[0];
-  Top2 top = {p0.x, p0.y, __float_as_int(p0.z), __float_as_int(p0.w)};
-  for (int q = 1; q < sp.nb; ++q) {
-    const float4 pq = pp[(size_t)q * 64];
-    top2_merge(top, pq.x, pq.y, __float_as_int(pq.z), __float_as_int(pq.w), geom);
-  }
-  emit_bid(A, o, list[o + u], top, eps);
 }
 
 __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
     int n, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     const float *__restrict__ max_inc, int *__restrict__ max_idx, const int *__restrict__ list,
-    const int *__restrict__ cnt, int *__restrict__ cnt_next) {
+    const int *__restrict__ cnt) {
   const int b = blockIdx.y;
   const int U = cnt[b];
-  if (blockIdx.x == 0 && threadIdx.x == 0) cnt_next[b] = 0;
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
     const int j = list[(size_t)b * n + u];
     const int tgt = bid[(size_t)b * n + j];
@@ -645,7 +666,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
     int n, int *__restrict__ assignment, int *__restrict__ assignment_inv,
     float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     float *__restrict__ max_inc, const int *__restrict__ max_idx, const int *__restrict__ list,
-    const int *__restrict__ cnt, int *__restrict__ list_next, int *__restrict__ cnt_next,
+    const int *__restrict__ cnt, const int *__restrict__ rank1, int *__restrict__ flags,
     f4 *__restrict__ tgt4, int last) {
   const int b = blockIdx.y;
   const int U = cnt[b];
@@ -657,7 +678,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       const int inv = assignment_inv[o + tgt];
       if (!last && inv != -1) {
         assignment[o + inv] = -1;
-        list_next[o + atomicAdd(&cnt_next[b], 1)] = inv;
+        flags[o + rank1[o + inv]] = 1;  // evicted: bids again
       }
       assignment_inv[o + tgt] = j;
       assignment[o + j] = tgt;
@@ -666,9 +687,39 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       reinterpret_cast<float *>(tgt4 + o + tgt)[3] = filter_target(np);  // keep the bid filter in sync
       max_inc[o + tgt] = -1e9f;
     } else {
-      list_next[o + atomicAdd(&cnt_next[b], 1)] = j;
+      flags[o + rank1[o + j]] = 1;  // lost: bids again
     }
   }
+}
+
+// next unassigned list = the flagged bidders in Morton-rank order (one workgroup per cloud), so
+// that the 64 bidders of a wave stay spatial neighbours in every iteration
+__global__ __launch_bounds__(1024) void emd_compact_kernel(int n, const int *__restrict__ perm1,
+                                                           int *__restrict__ flags,
+                                                           int *__restrict__ list_next,
+                                                           int *__restrict__ cnt_next) {
+  __shared__ int wsum[16];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const size_t o = (size_t)b * n;
+  const int per = n / 1024;  // n is a multiple of 1024
+  const int r0 = tid * per;
+  int c = 0;
+  for (int r = r0; r < r0 + per; ++r) c += flags[o + r];
+  int incl = c;
+  for (int m = 1; m < 64; m <<= 1) {
+    const int v = __shfl_up(incl, m);
+    if ((tid & 63) >= m) incl += v;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+  __syncthreads();
+  int pos = incl - c;
+  for (int w = 0; w < (tid >> 6); ++w) pos += wsum[w];
+  for (int r = r0; r < r0 + per; ++r)
+    if (flags[o + r]) {
+      flags[o + r] = 0;
+      list_next[o + pos++] = perm1[o + r];
+    }
+  if (tid == 1023) cnt_next[b] = pos;
 }
 
 __global__ __launch_bounds__(kThreads) void emd_calcdist_kernel(
@@ -727,7 +778,12 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.cell_of = reinterpret_cast<int *>(p); p += arr;
   ws.hist = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
   ws.bbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
-  ws.partial = reinterpret_cast<float *>(p);
+  ws.sbbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * (n / 64) * 32, 256);
+  ws.perm1 = reinterpret_cast<int *>(p); p += arr;
+  ws.rank1 = reinterpret_cast<int *>(p); p += arr;
+  ws.flags = reinterpret_cast<int *>(p); p += arr;
+  ws.hist1 = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
+  ws.bbox1 = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
   return ws;
 }
 
@@ -735,9 +791,9 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 11 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
-         2 * sn::align_up((size_t)b * n * 16, 256) + (size_t)b * kSortCells * 4 +
-         sn::align_up((size_t)b * 24, 256) + (size_t)b * 16 * 4 * 64 * 16;
+  return 14 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+         2 * sn::align_up((size_t)b * n * 16, 256) + 2 * (size_t)b * kSortCells * 4 +
+         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 64) * 32, 256);
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
@@ -757,27 +813,30 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
   cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz2, ws.bbox, ws.hist, ws.cell_of);
   cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist, ws.tperm, total);
+  cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz1, ws.bbox1, ws.hist1, ws.cell_of);
+  cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist1, ws.perm1, total);
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
+  emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
   emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
   const int g_env = kBlocksPerCloud;
   const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
   for (int it = 0; it < iters; ++it) {
     const int c = it & 1;
-    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx,
-                       reinterpret_cast<float4 *>(ws.partial)};
+    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx};
     // prices move by bid increments >= eps per iteration: a lower bound for every price
     const float price_floor = eps < 0.f ? eps * (float)it : 0.f;
     SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
-        b, g_env, n, eps, price_floor, xyz1, ws.price, ws.tgt4, ws.mstream, ws.bbox, ws.tperm,
-        ws.list[c], ws.cnt[c], bo, stats)));
-    emd_bid_finish_kernel<<<b, kBidThreads, 0, s>>>(g_env, n, eps, ws.list[c], ws.cnt[c], bo);
+        b, g_env, n, eps, price_floor, xyz1, ws.price, ws.tgt4, ws.mstream, ws.bbox, ws.sbbox,
+        ws.tperm, ws.list[c], ws.cnt[c], bo, stats)));
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
-                                                    ws.list[c], ws.cnt[c], ws.cnt[c ^ 1]);
+                                                    ws.list[c], ws.cnt[c]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
                                                     ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
-                                                    ws.list[c], ws.cnt[c], ws.list[c ^ 1],
-                                                    ws.cnt[c ^ 1], ws.tgt4, it == iters - 1);
+                                                    ws.list[c], ws.cnt[c], ws.rank1, ws.flags,
+                                                    ws.tgt4, it == iters - 1);
+    if (it + 1 < iters)
+      emd_compact_kernel<<<b, 1024, 0, s>>>(n, ws.perm1, ws.flags, ws.list[c ^ 1], ws.cnt[c ^ 1]);
   }
   emd_calcdist_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, assignment, dist);
   return sn::launch_status("sn_emd_forward");
