@@ -701,25 +701,41 @@ __global__ __launch_bounds__(1024) void emd_compact_kernel(int n, const int *__r
   __shared__ int wsum[16];
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)b * n;
-  const int per = n / 1024;  // n is a multiple of 1024
-  const int r0 = tid * per;
-  int c = 0;
-  for (int r = r0; r < r0 + per; ++r) c += flags[o + r];
-  int incl = c;
-  for (int m = 1; m < 64; m <<= 1) {
-    const int v = __shfl_up(incl, m);
-    if ((tid & 63) >= m) incl += v;
-  }
-  if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-  __syncthreads();
-  int pos = incl - c;
-  for (int w = 0; w < (tid >> 6); ++w) pos += wsum[w];
-  for (int r = r0; r < r0 + per; ++r)
-    if (flags[o + r]) {
-      flags[o + r] = 0;
-      list_next[o + pos++] = perm1[o + r];
+  // rank r = 4 (1024 i + tid) + e: every pass reads one coalesced int4 per lane
+  const int passes = n / 4096 > 0 ? n / 4096 : 1;  // n is a multiple of 1024
+  const int vec = n / 4;                            // int4 words per cloud
+  int base = 0;
+  for (int i = 0; i < passes; ++i) {
+    const int w = i * 1024 + tid;
+    int4 f = make_int4(0, 0, 0, 0);
+    if (w < vec) {
+      f = reinterpret_cast<const int4 *>(flags + o)[w];
+      if (f.x | f.y | f.z | f.w) reinterpret_cast<int4 *>(flags + o)[w] = make_int4(0, 0, 0, 0);
     }
-  if (tid == 1023) cnt_next[b] = pos;
+    const int c = f.x + f.y + f.z + f.w;
+    int incl = c;
+    for (int m = 1; m < 64; m <<= 1) {
+      const int v = __shfl_up(incl, m);
+      if ((tid & 63) >= m) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int pos = base + incl - c, total = 0;
+    for (int wv = 0; wv < 16; ++wv) {
+      if (wv < (tid >> 6)) pos += wsum[wv];
+      total += wsum[wv];
+    }
+    if (c > 0) {
+      const int r = 4 * w;
+      if (f.x) list_next[o + pos++] = perm1[o + r];
+      if (f.y) list_next[o + pos++] = perm1[o + r + 1];
+      if (f.z) list_next[o + pos++] = perm1[o + r + 2];
+      if (f.w) list_next[o + pos++] = perm1[o + r + 3];
+    }
+    base += total;
+    __syncthreads();
+  }
+  if (tid == 0) cnt_next[b] = base;
 }
 
 __global__ __launch_bounds__(kThreads) void emd_calcdist_kernel(

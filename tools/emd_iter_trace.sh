@@ -13,7 +13,7 @@ rows = [r for r in rows if "emd_" in r["Kernel_Name"]]
 last = max(i for i, r in enumerate(rows) if "emd_init" in r["Kernel_Name"])
 rows = rows[last:]
 def short(n):
-    for k in ("bid_kernel", "compact", "getmax", "assign", "init", "calcdist", "seed", "sbbox", "sort_count", "sort_scatter"):
+    for k in ("bid_kernel", "resolve", "compact", "getmax", "assign", "init", "calcdist", "seed", "sbbox", "sort_count", "sort_scatter"):
         if k in n: return k
     return n[:30]
 it, cur, t_prev = [], {}, None
@@ -23,7 +23,7 @@ for r in rows:
         it.append(cur); cur = {}
     cur[k] = d; cur.setdefault("t0", int(r["Start_Timestamp"])); cur["t1"] = int(r["End_Timestamp"])
 it.append(cur)
-keys = [k for k in ("bid_kernel", "getmax", "assign", "compact") if any(k in c for c in it)]
+keys = [k for k in ("bid_kernel", "resolve", "getmax", "assign", "compact") if any(k in c for c in it)]
 print("iter  " + "  ".join(f"{k[-12:]:>12}" for k in keys) + "   span_us")
 for i, c in enumerate(it):
     if "t0" not in c: continue

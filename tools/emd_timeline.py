@@ -10,15 +10,17 @@ dev = torch.device("cuda:0")
 B, N = 32, 16384
 g = torch.Generator().manual_seed(1234)
 x = torch.rand(B, N, 3, generator=g).to(dev); y = torch.rand(B, N, 3, generator=g).to(dev)
-for it in (2, 20, 50):
-    st = torch.zeros(8 + 1024 * 16 * 4, dtype=torch.int64, device=dev)
+for it in (1, 2, 10, 50):
+    st = torch.zeros(8 + 1024 * 16 * 8, dtype=torch.int64, device=dev)
     emd_forward_raw(x, y, 0.005, it, st); torch.cuda.synchronize()
-    r = st[8:].view(-1, 4).cpu().numpy().astype(np.float64)
-    last = r[:, 0] >= r[:, 0].max() - 100 * 2000      # records stamped in the last 2 ms
+    r = st[8:].view(-1, 8).cpu().numpy().astype(np.float64)
+    r = r[r[:, 0] > 0]
+    last = r[:, 0] >= r[:, 0].max() - 100 * (300 if it > 2 else 3000)   # records of the last launch (stamps within 0.3 / 3 ms)
     r = r[last]
     t0 = r[:, 0].min()
     start = (r[:, 0] - t0) / 100; setup = r[:, 1] / 100; scan = r[:, 2] / 100; post = r[:, 3] / 100
     end = start + setup + scan + post
     pc = lambda a: " ".join(f"{np.percentile(a, q):7.1f}" for q in (10, 50, 90, 99, 100))
-    print(f"iter {it}: waves {len(r)}  (us, p10 p50 p90 p99 max)")
-    print("   start", pc(start)); print("   setup", pc(setup)); print("   scan ", pc(scan)); print("   post ", pc(post)); print("   end  ", pc(end))
+    print(f"iter {it}: waves {len(r)} S={np.unique(r[:,6])}  (p10 p50 p90 p99 max)")
+    for name, a in (("start us", start), ("setup us", setup), ("scan us", scan), ("post us", post), ("end us", end), ("visited", r[:, 4]), ("batches", r[:, 5])):
+        print(f"   {name:9s}", pc(a))
