@@ -150,10 +150,11 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
     atomicMin(reinterpret_cast<unsigned *>(addr), __float_as_uint(v));
 }
 
-// Two prepared target streams per cloud.
-//  * tgt4[k] = {x, y, z, A'_k}, A'_k = filter_target(price_k): what the exact path and the
-//    precise filter read (one 16-byte load).  Written by emd_init_kernel, .w refreshed by
-//    emd_assign_kernel for the targets whose price changed.
+// Prepared target data per cloud, all in Morton order (stream position p holds target tperm[p]):
+//  * t4s[p] = {x, y, z, A'_k}, A'_k = filter_target(price_k), and pk[p] = {price_k, k}: what
+//    the precise filter and the exact path read, both addressed by the stream position of a hit
+//    (one round trip).  Written by emd_init_kernel, A' and the price refreshed by
+//    emd_assign_kernel for the targets whose price changed (rank2[k] = p).
 //  * mstream: the MFMA A-operand of the coarse filter, price independent (written once).
 //    u_kj = |t_k|^2 - 2 t_k . x_j is a [targets x 4] . [4 x bidders] product with rows
 //    (-2x, -2y, -2z, |t|^2) and columns (x, y, z, 1).  v_mfma_f32_16x16x4_f32 takes ONE float
@@ -161,6 +162,7 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
 //    4 such operands; lane l's four values sit in one float4:
 //      mstream[(superblock * 64 + l)].q = component (l >> 4) of target 64 sb + 16 q + (l & 15)
 //    so a wave fetches 64 targets with one coalesced global_load_dwordx4 per lane.
+//  * sbbox: the bounding box of every superblock, for the pruning test.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct EmdWs {
@@ -172,7 +174,9 @@ struct EmdWs {
   int *max_idx;
   int *list[2];
   int *cnt[2];
-  f4 *tgt4;      // [B, n]
+  f4 *t4s;       // [B, n] by stream position p: {x, y, z, A'} of target tperm[p]
+  float2 *pk;    // [B, n] by stream position: {price, target index bits}
+  int *rank2;    // [B, n] target index -> stream position
   f4 *mstream;   // [B, n/64, 64], targets in Morton order (position p holds target tperm[p])
   int *tperm;    // [B, n] sorted position -> target index
   int *cell_of;  // [B, n] sort scratch
@@ -202,12 +206,15 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
     ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
     ws.flags[e] = 0;
-    ws.tgt4[e] = f4{xyz2[e * 3 + 0], xyz2[e * 3 + 1], xyz2[e * 3 + 2], filter_target(0.f)};
-    {  // stream position p of this cloud holds target tperm[p]
+    {  // stream position p of this cloud holds target k = tperm[p]
       const long bb = e / n;
       const int p = (int)(e - bb * n);
-      const float *t = xyz2 + (bb * n + ws.tperm[e]) * 3;
+      const int k = ws.tperm[e];
+      const float *t = xyz2 + (bb * n + k) * 3;
       const float x = t[0], y = t[1], z = t[2];
+      ws.t4s[e] = f4{x, y, z, filter_target(0.f)};
+      ws.pk[e] = make_float2(0.f, __int_as_float(k));
+      ws.rank2[bb * n + k] = p;
       const float tt = (x * x + y * y) + z * z;
       float *m = reinterpret_cast<float *>(ws.mstream + (bb * (n >> 6) + (p >> 6)) * 64);
       const int q = (p >> 4) & 3, c = p & 15;
@@ -340,7 +347,7 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const
 // hit queue.  Level-1 hits are rare and scattered over the lanes, so they are not evaluated
 //   in place: (target, bidder) pairs are appended to a per-wave LDS queue and handled 64 at a
 //   time with every lane busy.
-// level 2 (precise filter) + exact path, per queued pair.  tgt4[k] is loaded and the
+// level 2 (precise filter) + exact path, per queued pair.  t4s / pk of the position are loaded and the
 //   exact-arithmetic test s <= R' |R'|, R' = A'_k - c'_j (derivation above) applied; the
 //   survivors get the reference's arithmetic (correctly rounded sqrt, fp64 detour) and are
 //   pushed into the bidder's top-2, which lives in LDS; lanes holding pairs of the same bidder
@@ -391,11 +398,11 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
   return __builtin_fmaf(r * __builtin_fabsf(r), 1.00000095367431640625f, base);
 }
 
-__global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
+__global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
     int B, int G, int n, float eps, float price_floor, const float *__restrict__ xyz1,
-    const float *__restrict__ price, const f4 *__restrict__ tgt4, const f4 *__restrict__ mstream,
-    const float *__restrict__ bbox, const float *__restrict__ sbbox, const int *__restrict__ tperm,
-    const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
+    const f4 *__restrict__ t4s, const float2 *__restrict__ pk, const int *__restrict__ rank2,
+    const f4 *__restrict__ mstream,
+    const float *__restrict__ bbox, const float *__restrict__ sbbox, const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
     long long *__restrict__ stats) {
   __shared__ WaveTab tabs[kBidWaves];
   __shared__ GroupAcc gacc[kBidWaves];
@@ -423,10 +430,10 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
   const int row = lane >> 4, col = lane & 15;
   const size_t o = (size_t)b * n;
   const float *__restrict__ p1 = xyz1 + o * 3;
-  const float *__restrict__ pr = price + o;
-  const f4 *__restrict__ t4 = tgt4 + o;
+  const f4 *__restrict__ t4 = t4s + o;
+  const float2 *__restrict__ pkc = pk + o;
+  const int *__restrict__ rk2 = rank2 + o;
   const int *__restrict__ lst = list + o;
-  const int *__restrict__ tp = tperm + o;
   WaveTab &T = tabs[wave];
 
   const int ngroups = (U + 63) >> 6;
@@ -475,6 +482,9 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
               blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], m));
               bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], m));
             }
+            // wave-uniform: keep them in SGPRs
+            blo[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(blo[a])));
+            bhi[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bhi[a])));
           }
         }
         // seed the filter with the bidder's previous two favourites under today's prices:
@@ -482,9 +492,10 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         float cm = -1e9f;
         const int pa = A.bid[o + j], pb = A.bid2[o + j];
         if (pa >= 0 && pb >= 0) {
-          const f4 ta = t4[pa], tb = t4[pb];
-          const float da = bid_value(ta.x, ta.y, ta.z, pr[pa], x1, y1, z1);
-          const float db = bid_value(tb.x, tb.y, tb.z, pr[pb], x1, y1, z1);
+          const int qa = rk2[pa], qb = rk2[pb];
+          const f4 ta = t4[qa], tb = t4[qb];
+          const float da = bid_value(ta.x, ta.y, ta.z, pkc[qa].x, x1, y1, z1);
+          const float db = bid_value(tb.x, tb.y, tb.z, pkc[qb].x, x1, y1, z1);
           cm = __builtin_fminf(da, db);
         }
         T.x[lane] = x1;
@@ -514,12 +525,14 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
       auto batch = [&](int first, int count) {
         const bool on = lane < count;
         const unsigned e = T.queue[first + (on ? lane : 0)];
-        const int k = tp[e & 0xfffffu], c = (int)(e >> 20);  // stream position -> target
-        const f4 t = t4[k];
+        const int c = (int)(e >> 20);
+        const f4 t = t4[e & 0xfffffu];       // both records are addressed by the stream position:
+        const float2 pq = pkc[e & 0xfffffu];  // one round trip for coordinates, A', price, index
+        const int k = __float_as_int(pq.y);
         const float sq = sq_dist(t.x, t.y, t.z, T.x[c], T.y[c], T.z[c]);
         bool pend = on && filter_pass(sq, t.w, filter_thr(T.cm[c]));  // level 2
         float d = 0.f;
-        if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pr[k]);
+        if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pq.x);
         volatile int *own = T.owner;
         while (__any(pend)) {  // lanes holding pairs of the same bidder take turns
           asm volatile("" ::: "memory");
@@ -547,6 +560,7 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
       auto refresh_reach = [&]() {
         float v = active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f;
         for (int m = 1; m < 64; m <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m));
+        v = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
         r2max = v > 0.f ? v * 1.0001f : v;
       };
       refresh_reach();
@@ -564,11 +578,17 @@ __global__ __launch_bounds__(kBidThreads, 8) void emd_bid_kernel(
         const int sbl = sb0 + lane;
         const bool mine = sbl < nsb && (sbl & (S - 1)) == seg;
         unsigned long long todo = __ballot(mine && worth(sbl));
+        f4 a_next = {0.f, 0.f, 0.f, 0.f};
+        int next_sb = -1;  // superblock whose operand is already in flight
         while (todo) {
           const int sb = sb0 + __builtin_ctzll(todo);
           todo &= todo - 1;
           const int kb = sb * 64;
-          const f4 a = ms[(size_t)sb * 64];
+          const f4 a = sb == next_sb ? a_next : ms[(size_t)sb * 64];
+          if (todo) {
+            next_sb = sb0 + __builtin_ctzll(todo);
+            a_next = ms[(size_t)next_sb * 64];
+          }
           bool drained = false;
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
     float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     float *__restrict__ max_inc, const int *__restrict__ max_idx, const int *__restrict__ list,
     const int *__restrict__ cnt, const int *__restrict__ rank1, int *__restrict__ flags,
-    f4 *__restrict__ tgt4, int last) {
+    const int *__restrict__ rank2, f4 *__restrict__ t4s, float2 *__restrict__ pk, int last) {
   const int b = blockIdx.y;
   const int U = cnt[b];
   const size_t o = (size_t)b * n;
@@ -684,7 +704,9 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       assignment[o + j] = tgt;
       const float np = price[o + tgt] + bid_inc[o + j];
       price[o + tgt] = np;
-      reinterpret_cast<float *>(tgt4 + o + tgt)[3] = filter_target(np);  // keep the bid filter in sync
+      const int pos = rank2[o + tgt];  // keep the bid kernel's records in sync
+      reinterpret_cast<float *>(t4s + o + pos)[3] = filter_target(np);
+      reinterpret_cast<float *>(pk + o + pos)[0] = np;
       max_inc[o + tgt] = -1e9f;
     } else {
       flags[o + rank1[o + j]] = 1;  // lost: bids again
@@ -788,7 +810,9 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
   ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
   ws.cnt[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
-  ws.tgt4 = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.t4s = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
+  ws.pk = reinterpret_cast<float2 *>(p); p += sn::align_up((size_t)b * n * 8, 256);
+  ws.rank2 = reinterpret_cast<int *>(p); p += arr;
   ws.mstream = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
   ws.tperm = reinterpret_cast<int *>(p); p += arr;
   ws.cell_of = reinterpret_cast<int *>(p); p += arr;
@@ -807,8 +831,8 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 14 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
-         2 * sn::align_up((size_t)b * n * 16, 256) + 2 * (size_t)b * kSortCells * 4 +
+  return 15 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+         2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
          2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 64) * 32, 256);
 }
 
@@ -843,14 +867,14 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     // prices move by bid increments >= eps per iteration: a lower bound for every price
     const float price_floor = eps < 0.f ? eps * (float)it : 0.f;
     SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
-        b, g_env, n, eps, price_floor, xyz1, ws.price, ws.tgt4, ws.mstream, ws.bbox, ws.sbbox,
-        ws.tperm, ws.list[c], ws.cnt[c], bo, stats)));
+        b, g_env, n, eps, price_floor, xyz1, ws.t4s, ws.pk, ws.rank2, ws.mstream, ws.bbox, ws.sbbox,
+        ws.list[c], ws.cnt[c], bo, stats)));
     emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
                                                     ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
                                                     ws.list[c], ws.cnt[c], ws.rank1, ws.flags,
-                                                    ws.tgt4, it == iters - 1);
+                                                    ws.rank2, ws.t4s, ws.pk, it == iters - 1);
     if (it + 1 < iters)
       emd_compact_kernel<<<b, 1024, 0, s>>>(n, ws.perm1, ws.flags, ws.list[c ^ 1], ws.cnt[c ^ 1]);
   }
