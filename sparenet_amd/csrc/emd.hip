@@ -356,9 +356,12 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const
 //   through, so the top-2 VALUES are those of the full scan; exact ties resolve through
 //   tie_key, which does not depend on the visiting order either.
 //
-// Work split as before: S = 2^k <= 64 waves share a group of 64 bidders, each scanning
-// n / S targets (a whole number of superblocks); up to 16 of them meet in LDS, the rest in
-// emd_bid_finish_kernel.
+// superblock pruning.  Bidders are served in Morton order (the unassigned list is rebuilt in
+//   rank order every iteration), so the 64 bidders of a wave are neighbours; the wave keeps
+//   their bounding box and the largest reach of their filters and only visits the superblocks
+//   whose bounding box lies within that reach (64 box tests at a time, lane = superblock).
+// Work split: S = 2^k <= 16 waves of ONE workgroup share a group of 64 bidders, wave s taking
+// the superblocks sb with sb mod S == s; their partial top-2's meet in LDS in arrival order.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ float min16(const f4 a, const f4 b, const f4 c, const f4 d) {
   const float m0 = __builtin_fminf(__builtin_fminf(a.x, a.y), a.z);

@@ -10,17 +10,15 @@ dev = torch.device("cuda:0")
 B, N = 32, 16384
 g = torch.Generator().manual_seed(1234)
 x = torch.rand(B, N, 3, generator=g).to(dev); y = torch.rand(B, N, 3, generator=g).to(dev)
-for it in (1, 2, 10, 50):
-    st = torch.zeros(8 + 1024 * 16 * 8, dtype=torch.int64, device=dev)
+for it in (1, 10, 50):
+    st = torch.zeros(8 + 1024 * 16 * 12, dtype=torch.int64, device=dev)
     emd_forward_raw(x, y, 0.005, it, st); torch.cuda.synchronize()
-    r = st[8:].view(-1, 8).cpu().numpy().astype(np.float64)
+    r = st[8:].view(-1, 12).cpu().numpy().astype(np.float64)
     r = r[r[:, 0] > 0]
-    last = r[:, 0] >= r[:, 0].max() - 100 * (300 if it > 2 else 3000)   # records of the last launch (stamps within 0.3 / 3 ms)
-    r = r[last]
-    t0 = r[:, 0].min()
-    start = (r[:, 0] - t0) / 100; setup = r[:, 1] / 100; scan = r[:, 2] / 100; post = r[:, 3] / 100
-    end = start + setup + scan + post
+    r = r[r[:, 0] >= r[:, 0].max() - 100 * (300 if it > 2 else 3000)]
     pc = lambda a: " ".join(f"{np.percentile(a, q):7.1f}" for q in (10, 50, 90, 99, 100))
-    print(f"iter {it}: waves {len(r)} S={np.unique(r[:,6])}  (p10 p50 p90 p99 max)")
-    for name, a in (("start us", start), ("setup us", setup), ("scan us", scan), ("post us", post), ("end us", end), ("visited", r[:, 4]), ("batches", r[:, 5])):
-        print(f"   {name:9s}", pc(a))
+    print(f"iter {it}: waves {len(r)}  (p10 p50 p90 p99 max)")
+    names = ["setup us", "scan us", "post us", "visited", "batches", "hit blocks", "hit us", "batch us", "worth us"]
+    for i, name in enumerate(names):
+        a = r[:, i + 1] / (100 if name.endswith("us") else 1)
+        print(f"   {name:10s}", pc(a))
