@@ -301,11 +301,12 @@ __global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(int *__restrict__ of
   }
 }
 
-// sorted payload: spt[pos] = (row, col), sid[pos] = point id; afterwards offs[c] is the END of cell c
+// sorted payload: srec[pos] = {row, col, feature (single-channel case), point id bits} -- one
+// 16-byte load per candidate in the gather; afterwards offs[c] is the END offset of cell c
 __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
-    const float *__restrict__ points, const int *__restrict__ batch_inds, int *__restrict__ offs,
-    float2 *__restrict__ spt, int *__restrict__ sid, int npoints, int batch, int h, int w,
-    int cells_x, int cells_y) {
+    const float *__restrict__ points, const float *__restrict__ feat,
+    const int *__restrict__ batch_inds, int *__restrict__ offs, float4 *__restrict__ srec,
+    int npoints, int channels, int batch, int h, int w, int cells_x, int cells_y) {
   for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
        pid += gridDim.x * blockDim.x) {
     const int b = batch_inds[pid];
@@ -314,8 +315,7 @@ __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
     const int c = cell_of_point(py, px, h, w, cells_x, cells_y);
     if (c < 0) continue;
     const int pos = atomicAdd(&offs[b * cells_y * cells_x + c], 1);
-    spt[pos] = make_float2(py, px);
-    sid[pos] = pid;
+    srec[pos] = make_float4(py, px, channels == 1 ? feat[pid] : 0.f, __int_as_float(pid));
   }
 }
 
@@ -328,7 +328,7 @@ struct GatherHit {
 template <int NR>
 __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
     const float *__restrict__ feat, const float *__restrict__ background,
-    const float2 *__restrict__ spt, const int *__restrict__ sid, const int *__restrict__ offs,
+    const float4 *__restrict__ srec, const int *__restrict__ offs,
     int channels, int batch, int h, int w, int cells_x, int cells_y, RadiiArg ra,
     float *__restrict__ out, int *__restrict__ out_ids) {
   constexpr int kQ = 128;
@@ -397,16 +397,19 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
     const int first_cell = cell_base + cyy * cells_x + c_lo;
     const int beg = first_cell > 0 ? offs[first_cell - 1] : 0;
     const int end = offs[cell_base + cyy * cells_x + c_hi];
+    float4 rec_next = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (beg + lane < end) rec_next = srec[beg + lane];
     for (int base = beg; base < end; base += 64) {
       const int j = base + lane;
+      const float4 rec = rec_next;
+      if (j + 64 < end) rec_next = srec[j + 64];  // the next 64 candidates are in flight
       float cpy = 0.f, cpx = 0.f, cf = 0.f;
       unsigned clow = 0;
       if (j < end) {
-        const float2 pt = spt[j];
-        const int pid = sid[j];
-        cpy = pt.x;
-        cpx = pt.y;
-        cf = feat[(size_t)pid * channels + c];
+        const int pid = __float_as_int(rec.w);
+        cpy = rec.x;
+        cpx = rec.y;
+        cf = channels == 1 ? rec.z : feat[(size_t)pid * channels + c];
         clow = 0xFFFFFFFEu - (unsigned)pid;
       }
       // Cull, 64 candidates at a time (lane = candidate): nearest pixel of the tile out of
@@ -851,7 +854,7 @@ constexpr float kTileMaxRadius = 16.f;  // larger kernels use the global scatter
 
 size_t tile_workspace_bytes(int npoints, int batch, int h, int w) {
   const size_t cells = (size_t)batch * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);
-  return sn::align_up(cells * 4, 256) + sn::align_up((size_t)npoints * 8, 256) + (size_t)npoints * 4;
+  return sn::align_up(cells * 4, 256) + (size_t)npoints * 16;
 }
 
 // largest fp32 s with sqrtf(s) <= radius, on the host (IEEE sqrtf is correctly rounded there too)
@@ -894,19 +897,19 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
   SN_REQUIRE(tiles / 4 + 1 < (1L << 31), "%s: too many tiles", fn);
   char *wp = static_cast<char *>(workspace);
   int *offs = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
-  float2 *spt = reinterpret_cast<float2 *>(wp); wp += sn::align_up((size_t)npoints * 8, 256);
-  int *sid = reinterpret_cast<int *>(wp);
+  float4 *srec = reinterpret_cast<float4 *>(wp);
   SN_HIP(hipMemsetAsync(offs, 0, (size_t)cells * 4, s));
   if (npoints > 0) {
     p2i_bin_count_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, offs, npoints, batch,
                                                              h, w, cells_x, cells_y);
     p2i_bin_scan_kernel<<<1, 1024, 0, s>>>(offs, (int)cells);
-    p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, offs, spt, sid,
-                                                               npoints, batch, h, w, cells_x, cells_y);
+    p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, feat, batch_inds, offs, srec,
+                                                               npoints, channels, batch, h, w, cells_x,
+                                                               cells_y);
   }
   const int blocks = (int)((tiles + 3) / 4);
 #define SN_GATHER(NR)                                                                         \
-  p2i_gather_max_kernel<NR><<<blocks, 256, 0, s>>>(feat, background, spt, sid, offs, channels, \
+  p2i_gather_max_kernel<NR><<<blocks, 256, 0, s>>>(feat, background, srec, offs, channels,      \
       batch, h, w, cells_x, cells_y, ra, out, out_ids)
   if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
   switch (nradii) {
