@@ -216,6 +216,16 @@ int sn_gridding_forward(const float *ptcloud, int b, int npts, int scale,
 int sn_gridding_backward(const float *grad_grid, const float *weights,
                          const int *indexes, int b, int npts, int nverts,
                          float *grad_ptcloud, void *stream);
+/* replaces gridding_distance.forward (cuda/gridding_loss/gridding_distance_cuda.cpp:
+ *          forward -> gridding_distance.cu:179-212, kernel :29-177): integer bounds
+ *          [min, max] per axis, grid[b, nverts, 8] with nverts = len_x len_y len_z (one
+ *          accumulator per vertex and corner role), weights[b,npts,8,3], indexes[b,npts,8]
+ *          (slot = vertex * 8 + corner).  gridding_distance.backward (:307-329) is
+ *          sn_gridding_backward with nverts * 8 slots (grad kernel :214-314). */
+int sn_gridding_dist_forward(const float *ptcloud, int b, int npts, int min_x,
+                             int max_x, int min_y, int max_y, int min_z, int max_z,
+                             float *grid, float *weights, int *indexes,
+                             void *stream);
 /* replaces gridding.rev_forward / rev_backward (gridding_cuda.cpp:69-91,96-97;
  *          gridding_reverse.cu:30-122, 124-236). grid[b,scale,scale,scale]. */
 int sn_gridding_reverse_forward(const float *grid, int b, int scale,

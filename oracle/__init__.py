@@ -235,6 +235,20 @@ def gridding_forward(ptcloud, scale):
     return grid, w, ix
 
 
+def gridding_dist_forward(ptcloud, bounds):
+    """ptcloud [B,n,3] (already scaled), bounds = (min_x, max_x, min_y, max_y, min_z, max_z) integers
+    -> grid [B, nverts, 8], weights [B,n,8,3], indexes [B,n,8] (cuda/gridding_loss)."""
+    pc, pp = _f(ptcloud)
+    b, n, _ = pc.shape
+    mnx, mxx, mny, mxy, mnz, mxz = [int(v) for v in bounds]
+    nverts = (mxx - mnx + 1) * (mxy - mny + 1) * (mxz - mnz + 1)
+    grid = np.zeros((b, nverts, 8), np.float32)
+    w = np.zeros((b, n, 8, 3), np.float32)
+    ix = np.zeros((b, n, 8), np.int32)
+    lib().oracle_gridding_dist_forward(pp, b, n, mnx, mxx, mny, mxy, mnz, mxz, _pf(grid), _pf(w), _pi(ix))
+    return grid, w, ix
+
+
 def gridding_backward(grad_grid, weights, indexes):
     gg, pg = _f(grad_grid)
     w, pw = _f(weights)

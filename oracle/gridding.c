@@ -50,6 +50,36 @@ void oracle_gridding_forward(const float *ptcloud, int b, int npts, int scale, f
     }
 }
 
+/* cuda/gridding_loss/gridding_distance.cu:29-177 (forward kernel), :179-212 (launcher):
+ * the gridding weights over an integer box, eight accumulators per vertex (slot =
+ * vertex * 8 + corner).  Sequential accumulation in point order. */
+void oracle_gridding_dist_forward(const float *ptcloud, int b, int npts, int min_x, int max_x,
+                                  int min_y, int max_y, int min_z, int max_z, float *grid,
+                                  float *weights, int *indexes) {
+  const int len_y = max_y - min_y + 1, len_z = max_z - min_z + 1;
+  const long nslots = (long)(max_x - min_x + 1) * len_y * len_z * 8;
+  for (size_t e = 0; e < (size_t)b * nslots; ++e) grid[e] = 0.f;
+  for (int i = 0; i < b; ++i)
+    for (int j = 0; j < npts; ++j) {
+      const float *p = ptcloud + ((size_t)i * npts + j) * 3;
+      int lo[3], up[3];
+      for (int a = 0; a < 3; ++a) corners(p[a], &lo[a], &up[a]);
+      float *w = weights + ((size_t)i * npts + j) * 24;
+      int *ix = indexes + ((size_t)i * npts + j) * 8;
+      for (int c = 0; c < 8; ++c) {
+        const int cx = (c & 4) ? up[0] : lo[0], cy = (c & 2) ? up[1] : lo[1],
+                  cz = (c & 1) ? up[2] : lo[2];
+        ix[c] = (((cx - min_x) * len_y + (cy - min_y)) * len_z + (cz - min_z)) * 8 + c;
+        w[c * 3 + 0] = 1 - fabsf(p[0] - cx);
+        w[c * 3 + 1] = 1 - fabsf(p[1] - cy);
+        w[c * 3 + 2] = 1 - fabsf(p[2] - cz);
+      }
+      for (int c = 0; c < 8; ++c)
+        if (ix[c] >= 0 && ix[c] < nslots)
+          grid[(size_t)i * nslots + ix[c]] += w[c * 3 + 0] * w[c * 3 + 1] * w[c * 3 + 2];
+    }
+}
+
 void oracle_gridding_backward(const float *grad_grid, const float *weights, const int *indexes,
                               int b, int npts, int nverts, float *grad_ptcloud) {
   for (int i = 0; i < b; ++i)

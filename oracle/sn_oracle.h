@@ -106,6 +106,9 @@ void oracle_p2i_sum_backward(const float *out_grad, const float *points,
  *      cuda/cubic_feature_sampling/cubic_feature_sampling.cu:29-102,135-174 */
 void oracle_gridding_forward(const float *ptcloud, int b, int npts, int scale,
                              float *grid, float *weights, int *indexes);
+void oracle_gridding_dist_forward(const float *ptcloud, int b, int npts, int min_x, int max_x,
+                                  int min_y, int max_y, int min_z, int max_z, float *grid,
+                                  float *weights, int *indexes);
 void oracle_gridding_backward(const float *grad_grid, const float *weights,
                               const int *indexes, int b, int npts, int nverts,
                               float *grad_ptcloud);

@@ -57,6 +57,40 @@ __global__ __launch_bounds__(256) void gridding_fwd_kernel(int npts, int s, int 
   }
 }
 
+// gridding distance (cuda/gridding_loss/gridding_distance.cu:29-177): the same trilinear
+// weights over an arbitrary integer box [min, max] per axis, but every vertex keeps EIGHT
+// accumulators, one per corner role: slot = vertex * 8 + c.  The backward is
+// gridding_bwd_kernel with nverts * 8 slots (the reference's grad kernel :214-314 reads the
+// slots the forward recorded).
+__global__ __launch_bounds__(256) void gridding_dist_fwd_kernel(
+    int npts, int min_x, int min_y, int min_z, int len_y, int len_z, int nslots,
+    const float *__restrict__ ptcloud, float *__restrict__ grid, float *__restrict__ weights,
+    int *__restrict__ indexes, long total) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long)gridDim.x * blockDim.x) {
+    const long b = e / npts;
+    const float px = ptcloud[e * 3 + 0], py = ptcloud[e * 3 + 1], pz = ptcloud[e * 3 + 2];
+    int lx, ux, ly, uy, lz, uz;
+    corners(px, lx, ux);
+    corners(py, ly, uy);
+    corners(pz, lz, uz);
+    float *w = weights + e * 24;
+    int *ix = indexes + e * 8;
+    float *g = grid + b * nslots;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const int cx = (c & 4) ? ux : lx, cy = (c & 2) ? uy : ly, cz = (c & 1) ? uz : lz;
+      const int idx = (((cx - min_x) * len_y + (cy - min_y)) * len_z + (cz - min_z)) * 8 + c;
+      const float wx = 1 - fabsf(px - cx), wy = 1 - fabsf(py - cy), wz = 1 - fabsf(pz - cz);
+      ix[c] = idx;
+      w[c * 3 + 0] = wx;
+      w[c * 3 + 1] = wy;
+      w[c * 3 + 2] = wz;
+      if (idx >= 0 && idx < nslots) unsafeAtomicAdd(g + idx, wx * wy * wz);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gridding_bwd_kernel(int npts, int nverts,
                                                            const float *__restrict__ grad_grid,
                                                            const float *__restrict__ weights,
@@ -242,6 +276,26 @@ extern "C" int sn_gridding_forward(const float *ptcloud, int b, int npts, int sc
     gridding_fwd_kernel<<<lin_blocks(total), 256, 0, st>>>(npts, s, nverts, ptcloud, grid, weights,
                                                            indexes, total);
   return sn::launch_status("sn_gridding_forward");
+}
+
+extern "C" int sn_gridding_dist_forward(const float *ptcloud, int b, int npts, int min_x, int max_x,
+                                        int min_y, int max_y, int min_z, int max_z, float *grid,
+                                        float *weights, int *indexes, void *stream) {
+  SN_REQUIRE(grid, "sn_gridding_dist_forward: null pointer");
+  SN_REQUIRE(b >= 1 && npts >= 0 && max_x >= min_x && max_y >= min_y && max_z >= min_z,
+             "sn_gridding_dist_forward: bad sizes / bounds");
+  const long lx = (long)max_x - min_x + 1, ly = (long)max_y - min_y + 1, lz = (long)max_z - min_z + 1;
+  SN_REQUIRE(lx * ly * lz * 8 < (1L << 31), "sn_gridding_dist_forward: grid too large");
+  const int nslots = (int)(lx * ly * lz * 8);
+  hipStream_t st = sn::as_stream(stream);
+  SN_HIP(hipMemsetAsync(grid, 0, (size_t)b * nslots * 4, st));
+  const long total = (long)b * npts;
+  if (total == 0) return 0;
+  SN_REQUIRE(ptcloud && weights && indexes, "sn_gridding_dist_forward: null pointer");
+  gridding_dist_fwd_kernel<<<lin_blocks(total), 256, 0, st>>>(npts, min_x, min_y, min_z, (int)ly, (int)lz,
+                                                              nslots, ptcloud, grid, weights, indexes,
+                                                              total);
+  return sn::launch_status("sn_gridding_dist_forward");
 }
 
 extern "C" int sn_gridding_backward(const float *grad_grid, const float *weights,

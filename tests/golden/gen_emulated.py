@@ -232,6 +232,51 @@ def gen_gridding():
                                                 "under tests/golden/gen/simt.h"))
 
 
+def gen_gridding_dist():
+    import oracle
+
+    g = "cuda/gridding_loss/gridding_distance.cu"
+    exe = compile_harness("emu_gridding_dist.cpp", {
+        "REF_GDIST_INC": extract(g, 22, 177, "gdist_fwd.inc"),
+        "REF_GDIST_GRAD_INC": extract(g, 213, 314, "gdist_bwd.inc")}, "emu_gridding_dist")
+    for name, b, npts, half, seed in [("griddist_2x300_h4", 2, 300, 4.0, 0), ("griddist_1x400_h6", 1, 400, 6.0, 1)]:
+        gen = torch.Generator().manual_seed(seed)
+        pt = (torch.rand(b, npts, 3, generator=gen) * 2 - 1) * half * torch.tensor([1.0, 0.6, 0.8])
+        pt[:, ::17] = torch.round(pt[:, ::17])          # integer coordinates: lower == upper branch
+        pt = pt.numpy().astype(np.float32)
+        # bounds as GriddingDistance.forward derives them (cuda/gridding_loss/__init__.py:62-80)
+        lo = np.floor(pt.reshape(-1, 3).min(0)) - 1
+        hi = np.ceil(pt.reshape(-1, 3).max(0)) + 1
+        bounds = [int(lo[0]), int(hi[0]), int(lo[1]), int(hi[1]), int(lo[2]), int(hi[2])]
+        nv = (bounds[1] - bounds[0] + 1) * (bounds[3] - bounds[2] + 1) * (bounds[5] - bounds[4] + 1)
+        gg = torch.rand(b, nv * 8, generator=gen).numpy()
+        raw = run(exe, struct.pack("ii6i", b, npts, *bounds), [pt, gg])
+        o = 0
+
+        def take(dtype, shape):
+            nonlocal o
+            cnt = int(np.prod(shape))
+            a = np.frombuffer(raw, dtype, cnt, o).reshape(shape)
+            o += 4 * cnt
+            return a
+
+        grid = take(np.float32, (b, nv, 8)); w = take(np.float32, (b, npts, 8, 3))
+        ix = take(np.int32, (b, npts, 8)); gpt = take(np.float32, (b, npts, 3))
+        og, ow, oi = oracle.gridding_dist_forward(pt, bounds)
+        ogp = oracle.gridding_backward(gg, w, ix)
+        exact = np.array_equal(ow, w) and np.array_equal(oi, ix)
+        close = np.allclose(og, grid, rtol=1e-5, atol=1e-6) and np.allclose(ogp, gpt, rtol=1e-5, atol=1e-6)
+        print(f"{name}: bounds={bounds} weights/indexes exact={exact}, sums close={close}, "
+              f"sum weights={grid.sum():.3f} (npts*b={npts * b})")
+        if not (exact and close):
+            print("   NOT stored -- investigate")
+            continue
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), ptcloud=pt, bounds=np.array(bounds, np.int32),
+                            grad_grid=gg, grid=grid, weights=w, indexes=ix, grad_ptcloud=gpt,
+                            provenance=np.array("reference gridding_distance.cu kernel text under "
+                                                "tests/golden/gen/simt.h"))
+
+
 def gen_cubic():
     import oracle
 
@@ -270,6 +315,7 @@ def gen_cubic():
 
 
 GENS = {"emd": gen_emd, "expansion": gen_expansion, "mds": gen_mds, "gridding": gen_gridding,
+        "gridding_dist": gen_gridding_dist,
         "cubic": gen_cubic}
 
 if __name__ == "__main__":
