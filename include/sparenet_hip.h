@@ -204,6 +204,23 @@ int sn_p2i_sum_backward(const float *out_grad, const float *points,
                         int channels, int batch, int h, int w, float radius,
                         float *points_grad, float *feat_grad, void *stream);
 
+/* ------------------------------------------------------- depth-map projection
+ * The per-view glue of ComputeDepthMaps.forward (utils/p2i_utils.py:211-228 and the NDC ->
+ * pixel rescale of cuda/p2i_op/__init__.py:117-121) fused into two small kernels each way:
+ * data[npoints,3] (all batch elements), matrix16 = P@V row major (HOST array), extent =
+ * image_size - 1.  Outputs: pixel[npoints,2] (row, col) for sn_p2i_max_forward[_multi],
+ * z[npoints] (projected depth), zminmax[2] (device scratch, order-preserving bits of the
+ * global min / max of z), feat[npoints] = 1 - (z - zmin) / (zmax - zmin).
+ * Backward: g_pixel / g_feat may be NULL; workspace32 = 32 bytes of device scratch;
+ * includes the gradient paths through zmin / zmax as torch's autograd does. */
+int sn_depth_project_forward(const float *data, long npoints, const float *matrix16,
+                             float extent, float *pixel, float *z,
+                             unsigned *zminmax, float *feat, void *stream);
+int sn_depth_project_backward(const float *data, long npoints, const float *matrix16,
+                              float extent, const float *z, const unsigned *zminmax,
+                              const float *g_pixel, const float *g_feat,
+                              void *workspace32, float *g_data, void *stream);
+
 /* ----------------------------------------------------------------- gridding
  * replaces gridding.forward / backward (cuda/gridding/gridding_cuda.cpp:44-67,
  *          94-95; gridding.cu:29-211, 213-335).  ptcloud[b,npts,3] already

@@ -1,0 +1,207 @@
+// depth_project.hip -- the per-view glue of ComputeDepthMaps as two small kernels each way.
+//
+// Reference: utils/p2i_utils.py:211-228 (forward of one view), executed there as ~25 torch ops
+// per view (expand the 4x4 matrix per point, bmm, divide by w, stack (-y, x), global min / max of
+// z, depth feature, NDC -> pixel rescale inside p2i, cuda/p2i_op/__init__.py:117-121) and as many
+// autograd nodes on the way back:
+//   o      = M [x y z 1]^T,  pos = o.xyz / o.w
+//   pixel  = ((-pos.y, pos.x) + 1) / 2 * (S - 1)                (row, col)
+//   feat   = 1 - (pos.z - zmin) / (zmax - zmin),  zmin / zmax over the WHOLE tensor
+// Backward: the chain rule of exactly these expressions, including the paths through zmin and
+// zmax (torch's full-reduction min / max send their gradient evenly to every element that
+// attains the extreme).
+#include "common.hpp"
+
+namespace {
+
+struct Mat4 {
+  float m[16];  // row major
+};
+
+__device__ __forceinline__ unsigned ord_bits(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_bits(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__device__ __forceinline__ void transform(const Mat4 &M, float x, float y, float z, float o[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    o[r] = __builtin_fmaf(M.m[r * 4 + 2], z, __builtin_fmaf(M.m[r * 4 + 1], y, M.m[r * 4] * x)) +
+           M.m[r * 4 + 3];
+}
+
+__global__ __launch_bounds__(256) void depth_project_kernel(const float *__restrict__ data, long n,
+                                                            Mat4 M, float extent,
+                                                            float2 *__restrict__ pixel,
+                                                            float *__restrict__ zbuf,
+                                                            unsigned *__restrict__ zminmax) {
+  __shared__ unsigned red[2][4];
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float o[4];
+    transform(M, data[i * 3 + 0], data[i * 3 + 1], data[i * 3 + 2], o);
+    const float px = o[0] / o[3], py = o[1] / o[3], pz = o[2] / o[3];
+    pixel[i] = make_float2((-py + 1.f) / 2.f * extent, (px + 1.f) / 2.f * extent);
+    zbuf[i] = pz;
+    const unsigned k = ord_bits(pz);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    const unsigned a = (unsigned)__shfl_xor((int)lo, m), b = (unsigned)__shfl_xor((int)hi, m);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = lo;
+    red[1][threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      lo = red[0][w] < lo ? red[0][w] : lo;
+      hi = red[1][w] > hi ? red[1][w] : hi;
+    }
+    atomicMin(zminmax + 0, lo);
+    atomicMax(zminmax + 1, hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_feature_kernel(const float *__restrict__ zbuf, long n,
+                                                            const unsigned *__restrict__ zminmax,
+                                                            float *__restrict__ feat) {
+  const float zmin = unord_bits(zminmax[0]), zmax = unord_bits(zminmax[1]);
+  const float range = zmax - zmin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    feat[i] = 1.0f - (zbuf[i] - zmin) / range;
+}
+
+// sums for the zmin / zmax paths: S_a = sum g_f (zmax - z) / r^2, S_c = sum g_f (z - zmin) / r^2,
+// and how many points attain each extreme
+__global__ __launch_bounds__(256) void depth_reduce_kernel(const float *__restrict__ zbuf,
+                                                           const float *__restrict__ g_feat, long n,
+                                                           const unsigned *__restrict__ zminmax,
+                                                           double *__restrict__ sums,
+                                                           unsigned *__restrict__ counts) {
+  __shared__ double red[2][4];
+  __shared__ unsigned cred[2][4];
+  const float zmin = unord_bits(zminmax[0]), zmax = unord_bits(zminmax[1]);
+  const double r = (double)zmax - (double)zmin, r2 = r * r;
+  double sa = 0.0, sc = 0.0;
+  unsigned na = 0, nc = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float z = zbuf[i];
+    const double g = g_feat[i];
+    sa += g * ((double)zmax - (double)z) / r2;
+    sc += g * ((double)z - (double)zmin) / r2;
+    na += z == zmin;
+    nc += z == zmax;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    sa += __shfl_xor(sa, m);
+    sc += __shfl_xor(sc, m);
+    na += (unsigned)__shfl_xor((int)na, m);
+    nc += (unsigned)__shfl_xor((int)nc, m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sa;
+    red[1][threadIdx.x >> 6] = sc;
+    cred[0][threadIdx.x >> 6] = na;
+    cred[1][threadIdx.x >> 6] = nc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      sa += red[0][w];
+      sc += red[1][w];
+      na += cred[0][w];
+      nc += cred[1][w];
+    }
+    atomicAdd(sums + 0, sa);
+    atomicAdd(sums + 1, sc);
+    atomicAdd(counts + 0, na);
+    atomicAdd(counts + 1, nc);
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_project_bwd_kernel(
+    const float *__restrict__ data, long n, Mat4 M, float extent, const float *__restrict__ zbuf,
+    const unsigned *__restrict__ zminmax, const float2 *__restrict__ g_pixel,
+    const float *__restrict__ g_feat, const double *__restrict__ sums,
+    const unsigned *__restrict__ counts, float *__restrict__ g_data) {
+  const float zmin = unord_bits(zminmax[0]), zmax = unord_bits(zminmax[1]);
+  const float range = zmax - zmin;
+  const float ga = g_feat ? (float)(sums[0] / (double)counts[0]) : 0.f;
+  const float gc = g_feat ? (float)(sums[1] / (double)counts[1]) : 0.f;
+  const float half = extent * 0.5f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float o[4];
+    transform(M, data[i * 3 + 0], data[i * 3 + 1], data[i * 3 + 2], o);
+    const float z = zbuf[i];
+    float gpz = 0.f;
+    if (g_feat) gpz = -g_feat[i] / range + (z == zmin ? ga : 0.f) + (z == zmax ? gc : 0.f);
+    float gpx = 0.f, gpy = 0.f;
+    if (g_pixel) {
+      const float2 gp = g_pixel[i];  // d row / d pos.y = -extent/2, d col / d pos.x = extent/2
+      gpy = -gp.x * half;
+      gpx = gp.y * half;
+    }
+    const float iw = 1.0f / o[3];
+    const float go0 = gpx * iw, go1 = gpy * iw, go2 = gpz * iw;
+    const float go3 = -(gpx * o[0] + gpy * o[1] + gpz * o[2]) * iw * iw;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      g_data[i * 3 + c] = M.m[c] * go0 + M.m[4 + c] * go1 + M.m[8 + c] * go2 + M.m[12 + c] * go3;
+  }
+}
+
+int blocks_for(long n) {
+  const long b = (n + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+
+}  // namespace
+
+extern "C" int sn_depth_project_forward(const float *data, long npoints, const float *matrix16,
+                                        float extent, float *pixel, float *z,
+                                        unsigned *zminmax, float *feat, void *stream) {
+  SN_REQUIRE(matrix16 && zminmax, "sn_depth_project_forward: null pointer");
+  SN_REQUIRE(npoints >= 0, "sn_depth_project_forward: npoints < 0");
+  hipStream_t s = sn::as_stream(stream);
+  const unsigned init[2] = {0xffffffffu, 0u};
+  SN_HIP(hipMemcpyAsync(zminmax, init, 8, hipMemcpyHostToDevice, s));
+  if (npoints == 0) return 0;
+  SN_REQUIRE(data && pixel && z && feat, "sn_depth_project_forward: null pointer");
+  Mat4 M;
+  for (int i = 0; i < 16; ++i) M.m[i] = matrix16[i];
+  depth_project_kernel<<<blocks_for(npoints), 256, 0, s>>>(data, npoints, M, extent,
+                                                         reinterpret_cast<float2 *>(pixel), z, zminmax);
+  depth_feature_kernel<<<blocks_for(npoints), 256, 0, s>>>(z, npoints, zminmax, feat);
+  return sn::launch_status("sn_depth_project_forward");
+}
+
+extern "C" int sn_depth_project_backward(const float *data, long npoints, const float *matrix16,
+                                         float extent, const float *z, const unsigned *zminmax,
+                                         const float *g_pixel, const float *g_feat,
+                                         void *workspace32, float *g_data, void *stream) {
+  SN_REQUIRE(matrix16 && zminmax && workspace32, "sn_depth_project_backward: null pointer");
+  if (npoints == 0) return 0;
+  SN_REQUIRE(data && z && g_data, "sn_depth_project_backward: null pointer");
+  hipStream_t s = sn::as_stream(stream);
+  Mat4 M;
+  for (int i = 0; i < 16; ++i) M.m[i] = matrix16[i];
+  double *sums = static_cast<double *>(workspace32);
+  unsigned *counts = reinterpret_cast<unsigned *>(sums + 2);
+  if (g_feat) {
+    SN_HIP(hipMemsetAsync(workspace32, 0, 32, s));
+    depth_reduce_kernel<<<blocks_for(npoints) < 256 ? blocks_for(npoints) : 256, 256, 0, s>>>(
+        z, g_feat, npoints, zminmax, sums, counts);
+  }
+  depth_project_bwd_kernel<<<blocks_for(npoints), 256, 0, s>>>(
+      data, npoints, M, extent, z, zminmax, reinterpret_cast<const float2 *>(g_pixel), g_feat, sums,
+      counts, g_data);
+  return sn::launch_status("sn_depth_project_backward");
+}

@@ -15,9 +15,12 @@ The camera matrices are evaluated with the same fp32 torch operations as the ref
 so the eight P@V matrices agree bit for bit (tests/golden/depthmaps_*.npz); the
 per-point transform is a [B*N,3]x[3,4] product instead of B*N expanded 4x4 bmm's.
 """
+import ctypes
 import math
 
 import torch
+
+from sparenet_amd import _lib
 
 from sparenet_amd.cuda.p2i_op import P2IMaxFunction, P2IMaxMultiFunction, p2i  # noqa: F401
 
@@ -91,6 +94,53 @@ def transform(matrix, points):
     return out[:, :3] / out[:, 3:4]
 
 
+class DepthProjectFunction(torch.autograd.Function):
+    """(data [B,N,3], P@V as 16 host floats, image_size) -> (pixel_ijs [B*N,2], point_features
+    [B*N,1]): ComputeDepthMaps.project() followed by p2i's NDC -> pixel rescale, as two HIP
+    kernels each way (sn_depth_project_forward / _backward) instead of ~25 torch ops and their
+    autograd nodes per view."""
+
+    @staticmethod
+    def forward(ctx, data, matrix16, image_size):
+        pts = data.contiguous().float().view(-1, 3)
+        n = pts.size(0)
+        dev = pts.device
+        pixel = torch.empty(n, 2, device=dev)
+        feat = torch.empty(n, 1, device=dev)
+        z = torch.empty(n, device=dev)
+        zminmax = torch.empty(2, dtype=torch.int32, device=dev)
+        mat = (ctypes.c_float * 16)(*matrix16)
+        extent = float(image_size - 1)
+        with torch.cuda.device_of(pts):
+            code = _lib.lib().sn_depth_project_forward(
+                _lib.fptr(pts, "data"), ctypes.c_long(n), mat, _lib.cfloat(extent),
+                _lib.fptr(pixel, "pixel"), _lib.fptr(z, "z"), ctypes.c_void_p(zminmax.data_ptr()),
+                _lib.fptr(feat, "feat"), _lib.stream_of(pts))
+        _lib.check(code, "sn_depth_project_forward")
+        ctx.save_for_backward(pts, z, zminmax)
+        ctx.mat, ctx.extent, ctx.shape = mat, extent, data.shape
+        return pixel, feat
+
+    @staticmethod
+    def backward(ctx, g_pixel, g_feat):
+        pts, z, zminmax = ctx.saved_tensors
+        n = pts.size(0)
+        g_data = torch.empty_like(pts)
+        ws = torch.empty(32, dtype=torch.uint8, device=pts.device)
+        gp = g_pixel.contiguous().float() if g_pixel is not None else None
+        gf = g_feat.contiguous().float() if g_feat is not None else None
+        null = ctypes.c_void_p(0)
+        with torch.cuda.device_of(pts):
+            code = _lib.lib().sn_depth_project_backward(
+                _lib.fptr(pts, "data"), ctypes.c_long(n), ctx.mat, _lib.cfloat(ctx.extent),
+                _lib.fptr(z, "z"), ctypes.c_void_p(zminmax.data_ptr()),
+                _lib.fptr(gp, "g_pixel") if gp is not None else null,
+                _lib.fptr(gf, "g_feat") if gf is not None else null,
+                ctypes.c_void_p(ws.data_ptr()), _lib.fptr(g_data, "g_data"), _lib.stream_of(pts))
+        _lib.check(code, "sn_depth_project_backward")
+        return g_data.view(ctx.shape), None, None
+
+
 class ComputeDepthMaps(torch.nn.Module):
     def __init__(self, projection: str = "orthorgonal", eyepos_scale: float = 1.0,
                  image_size: int = 256):
@@ -120,6 +170,7 @@ class ComputeDepthMaps(torch.nn.Module):
         self.register_buffer("_extent", torch.tensor([[image_size - 1.0, image_size - 1.0]], **f32),
                              persistent=False)
         self.pre_matrix_list = [m.unsqueeze(0) for m in mats]
+        self._host_mats = [[float(v) for v in m.reshape(-1).tolist()] for m in mats]
         self._batch_inds_cache = {}
 
     def _batch_inds(self, batch, npoints, device):
@@ -144,14 +195,19 @@ class ComputeDepthMaps(torch.nn.Module):
         if view_id >= self.num_views:
             return None
         batch, npoints = data.size(0), data.size(1)
-        pos_ijs, point_features = self.project(data, view_id)
         background = torch.zeros(batch, 1, self.image_size, self.image_size, dtype=data.dtype,
                                  device=data.device)
         batch_inds = self._batch_inds(batch, npoints, data.device)
-        # the reference calls p2i() once per radius (:230-251); the NDC -> pixel rescale that p2i()
-        # performs (cuda/p2i_op/__init__.py:117-121), the zero background and the points do not
-        # depend on the radius, so they are hoisted and up to four radii share one splat pass
-        pixel_ijs = (pos_ijs + 1) / 2 * self._extent.to(device=data.device, dtype=data.dtype)
+        # the reference calls p2i() once per radius (:230-251); the projection, the depth feature,
+        # the NDC -> pixel rescale that p2i() performs (cuda/p2i_op/__init__.py:117-121), the zero
+        # background and the points do not depend on the radius, so they are computed once (on
+        # the GPU by the fused projection kernels) and up to four radii share one splat pass
+        if data.is_cuda and data.dtype == torch.float32:
+            pixel_ijs, point_features = DepthProjectFunction.apply(data, self._host_mats[view_id],
+                                                                   self.image_size)
+        else:
+            pos_ijs, point_features = self.project(data, view_id)
+            pixel_ijs = (pos_ijs + 1) / 2 * self._extent.to(device=data.device, dtype=data.dtype)
         radii = [float(r) for r in radius_list]
         maps = []
         for i in range(0, len(radii), 4):

@@ -221,6 +221,34 @@ def test_hip_p2i_autograd_vs_oracle(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("projection", ["orthorgonal", "perspective"])
+def test_hip_fused_projection_matches_torch_glue(projection, dev):
+    """DepthProjectFunction (sn_depth_project_*) against the torch mirror of the reference glue
+    (ComputeDepthMaps.project + the NDC -> pixel rescale), values and gradients, including the
+    gradient paths through the global zmin / zmax with several points attaining them."""
+    from sparenet_amd.utils.p2i_utils import ComputeDepthMaps, DepthProjectFunction
+
+    g = torch.Generator().manual_seed(21)
+    cdm = ComputeDepthMaps(projection, 1.0, 64).to(dev)
+    base = (torch.rand(3, 500, 3, generator=g) - 0.5)
+    base[1, 7] = base[0, 3]          # duplicated points: ties at whatever extreme they reach
+    base[2, 9] = base[0, 3]
+    wp = torch.rand(1500, 2, generator=g).to(dev)
+    wf = torch.rand(1500, 1, generator=g).to(dev)
+    for v in (0, 3, 6):
+        d1 = base.clone().to(dev).requires_grad_(True)
+        pos_ijs, feat = cdm.project(d1, v)
+        pix = (pos_ijs + 1) / 2 * 63.0
+        ((pix * wp).sum() + (feat * wf).sum()).backward()
+        d2 = base.clone().to(dev).requires_grad_(True)
+        pix2, feat2 = DepthProjectFunction.apply(d2, cdm._host_mats[v], 64)
+        ((pix2 * wp).sum() + (feat2 * wf).sum()).backward()
+        np.testing.assert_allclose(pix2.detach().cpu().numpy(), pix.detach().cpu().numpy(), rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(feat2.detach().cpu().numpy(), feat.detach().cpu().numpy(), rtol=1e-5, atol=3e-6)
+        np.testing.assert_allclose(d2.grad.cpu().numpy(), d1.grad.cpu().numpy(), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.gpu
 def test_hip_depthmaps_vs_reference_golden(golden_dir, dev):
     """End to end ComputeDepthMaps on the GPU against maps rendered by the imported
     reference (CPU torch glue + reference functor semantics)."""
