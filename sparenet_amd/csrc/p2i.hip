@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256) void p2i_max_splat_kernel(
 // visiting order.  All radii of a ComputeDepthMaps call share the binning, the fetches and the
 // squared distances; the finished tile is written once as values + ids.
 // ---------------------------------------------------------------------------------------
+#ifndef SN_P2I_DRAIN_STEPS
+#define SN_P2I_DRAIN_STEPS 0
+#endif
 constexpr int kCell = 8;
 constexpr int kMaxRadii = 4;
 
@@ -394,9 +397,15 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
     if (cyy < 0 || cyy >= cells_y) continue;  // wave-uniform
     const int c_lo = cx - ra.halo > 0 ? cx - ra.halo : 0;
     const int c_hi = cx + ra.halo < cells_x - 1 ? cx + ra.halo : cells_x - 1;
-    const int first_cell = cell_base + cyy * cells_x + c_lo;
+    // the tile's own row is walked own cell first, then its left and right neighbours
+    const int nparts = step == 0 ? 3 : 1;
+    for (int part = 0; part < nparts; ++part) {
+    const int p_lo = step == 0 ? (part == 0 ? cx : (part == 1 ? c_lo : cx + 1)) : c_lo;
+    const int p_hi = step == 0 ? (part == 0 ? cx : (part == 1 ? cx - 1 : c_hi)) : c_hi;
+    if (p_lo > p_hi) continue;
+    const int first_cell = cell_base + cyy * cells_x + p_lo;
     const int beg = first_cell > 0 ? offs[first_cell - 1] : 0;
-    const int end = offs[cell_base + cyy * cells_x + c_hi];
+    const int end = offs[cell_base + cyy * cells_x + p_hi];
     float4 rec_next = make_float4(0.f, 0.f, 0.f, 0.f);
     if (beg + lane < end) rec_next = srec[beg + lane];
     for (int base = beg; base < end; base += 64) {
@@ -438,13 +447,15 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
         const float dx = fx - px, dy = fy - py;
         const float s2 = sq2(dx, dy);
         const float f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), i));
+        // feature * weight <= f * max(w +- 2e-5, 0): the slack goes up for f >= 0, down otherwise
+        const float w_slack = f >= 0.f ? 2e-5f : -2e-5f;  // wave-uniform
         const float rad = __builtin_amdgcn_sqrtf(s2);  // ~1 ulp: only feeds the bound
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
           if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
           const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
-          const float wq = __builtin_amdgcn_cosf(rad * ra.rev_scale[k]) * 0.5f + 0.5f;
-          const float ub = f >= 0.f ? f * (wq + 2e-5f) : f * __builtin_fmaxf(wq - 2e-5f, 0.f);
+          const float wq = __builtin_fmaf(__builtin_amdgcn_cosf(rad * ra.rev_scale[k]), 0.5f, 0.5f + w_slack);
+          const float ub = f * __builtin_fmaxf(wq, 0.f);
           const bool pass = ink && ub >= best[k];  // can still reach (or tie with) the best
           const unsigned long long m = __ballot(pass);
           if (m) {
@@ -462,9 +473,10 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
         }
       }
     }
-    if (step == 0 && qn > 0) {  // the tile's own cell row: establish the bests early
+    if (step <= SN_P2I_DRAIN_STEPS && qn > 0) {  // near cells: establish the bests early
       drain(0, qn);
       qn = 0;
+    }
     }
   }
   if (qn > 0) drain(0, qn);

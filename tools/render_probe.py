@@ -1,6 +1,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1234)
