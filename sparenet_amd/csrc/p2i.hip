@@ -278,26 +278,41 @@ __global__ __launch_bounds__(256) void p2i_bin_count_kernel(
   }
 }
 
-// in-place exclusive scan of the cell counts (one workgroup)
-__global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(int *__restrict__ offs, int T) {
+// exclusive scan of the cell counts, one workgroup per image: the workgroup first adds up the
+// counts of all earlier images (its base offset), then scans its own cells.  offs_out may not
+// alias counts (other workgroups still read them).
+__global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(const int *__restrict__ counts,
+                                                            int *__restrict__ offs_out,
+                                                            int cells_per_image) {
   __shared__ int wsum[16];
   __shared__ int carry;
-  const int tid = threadIdx.x;
-  if (tid == 0) carry = 0;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  int before = 0;
+  for (long i = tid; i < (long)b * cells_per_image; i += 1024) before += counts[i];
+  for (int m = 1; m < 64; m <<= 1) before += __shfl_xor(before, m);
+  if ((tid & 63) == 0) wsum[tid >> 6] = before;
   __syncthreads();
-  for (int base = 0; base < T; base += 1024) {
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    carry = t;
+  }
+  __syncthreads();
+  const int *c = counts + (size_t)b * cells_per_image;
+  int *o = offs_out + (size_t)b * cells_per_image;
+  for (int base = 0; base < cells_per_image; base += 1024) {
     const int i = base + tid;
-    const int v = i < T ? offs[i] : 0;
+    const int v = i < cells_per_image ? c[i] : 0;
     int incl = v;
     for (int m = 1; m < 64; m <<= 1) {
-      const int o = __shfl_up(incl, m);
-      if ((tid & 63) >= m) incl += o;
+      const int u = __shfl_up(incl, m);
+      if ((tid & 63) >= m) incl += u;
     }
     if ((tid & 63) == 63) wsum[tid >> 6] = incl;
     __syncthreads();
     int pre = carry;
     for (int wv = 0; wv < (tid >> 6); ++wv) pre += wsum[wv];
-    if (i < T) offs[i] = pre + incl - v;
+    if (i < cells_per_image) o[i] = pre + incl - v;
     __syncthreads();
     if (tid == 1023) carry = pre + incl;
     __syncthreads();
@@ -866,7 +881,7 @@ constexpr float kTileMaxRadius = 16.f;  // larger kernels use the global scatter
 
 size_t tile_workspace_bytes(int npoints, int batch, int h, int w) {
   const size_t cells = (size_t)batch * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);
-  return sn::align_up(cells * 4, 256) + (size_t)npoints * 16;
+  return 2 * sn::align_up(cells * 4, 256) + (size_t)npoints * 16;
 }
 
 // largest fp32 s with sqrtf(s) <= radius, on the host (IEEE sqrtf is correctly rounded there too)
@@ -908,17 +923,18 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
   const long tiles = cells * channels;
   SN_REQUIRE(tiles / 4 + 1 < (1L << 31), "%s: too many tiles", fn);
   char *wp = static_cast<char *>(workspace);
+  int *counts = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   int *offs = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   float4 *srec = reinterpret_cast<float4 *>(wp);
-  SN_HIP(hipMemsetAsync(offs, 0, (size_t)cells * 4, s));
-  if (npoints > 0) {
-    p2i_bin_count_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, offs, npoints, batch,
+  SN_HIP(hipMemsetAsync(counts, 0, (size_t)cells * 4, s));
+  if (npoints > 0)
+    p2i_bin_count_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, counts, npoints, batch,
                                                              h, w, cells_x, cells_y);
-    p2i_bin_scan_kernel<<<1, 1024, 0, s>>>(offs, (int)cells);
+  p2i_bin_scan_kernel<<<batch, 1024, 0, s>>>(counts, offs, cells_x * cells_y);
+  if (npoints > 0)
     p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, feat, batch_inds, offs, srec,
                                                                npoints, channels, batch, h, w, cells_x,
                                                                cells_y);
-  }
   const int blocks = (int)((tiles + 3) / 4);
 #define SN_GATHER(NR)                                                                         \
   p2i_gather_max_kernel<NR><<<blocks, 256, 0, s>>>(feat, background, srec, offs, channels,      \
