@@ -215,6 +215,20 @@ def other_ops(dev, pred, mean_mst):
     out = {}
     idx = minimum_density_sample(cloud, N, mean_mst)
     out["mds_19384_to_16384"] = ms(lambda: minimum_density_sample(cloud, N, mean_mst))
+    # the same op on surface-like data: 32 compact patches of 512 points on a sphere of radius 0.5
+    # (what a decoder's primitives look like) + 3000 points of the partial input; the expansion's
+    # own mean_mst_length is then ~0.01 instead of ~0.05 and the cut radius covers ~5 % of the cloud
+    from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
+    v = torch.randn(B, N, 3, generator=g)
+    v = 0.5 * v / v.norm(dim=2, keepdim=True)
+    key = (torch.atan2(v[..., 1], v[..., 0]) * 4).floor() * 100 + (v[..., 2] * 8).floor()
+    surf = torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous().to(dev)
+    _, _, mml_s = expansionPenaltyModule()(surf, PRIM, ALPHA)
+    cloud_s = torch.cat([surf, surf[:, :3000] + 0.01 * torch.randn(B, 3000, 3, generator=g).to(dev)],
+                        dim=1).contiguous()
+    out["mds_19384_to_16384_surface"] = ms(lambda: minimum_density_sample(cloud_s, N, mml_s))
+    out["mds_surface_mean_mst_length"] = float(mml_s.mean())
+    out["mds_uniform_mean_mst_length"] = float(mean_mst.mean())
     feat = torch.cat([cloud, cloud[:, :, :1]], dim=2).transpose(1, 2).contiguous()   # [32,4,19384]
     out["gather_c4"] = ms(lambda: gather_operation(feat, idx))
     pts = ((pred.detach() - 0.5) * 1.9).requires_grad_(True)              # inside (-1,1)
