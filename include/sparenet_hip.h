@@ -230,6 +230,13 @@ int sn_depth_project_backward(const float *data, long npoints, const float *matr
 int sn_gridding_forward(const float *ptcloud, int b, int npts, int scale,
                         float *grid, float *weights, int *indexes,
                         void *stream);
+/* The same with the reference module's padding rule done in the kernel: rows whose three
+ * (already scaled) coordinates sum to zero are padding and contribute nothing
+ * (cuda/gridding/__init__.py:41-47 filters them per sample on the host); their weights
+ * are written as 0 and their indexes as -1, so the backward gives them a zero gradient. */
+int sn_gridding_forward_padded(const float *ptcloud, int b, int npts, int scale,
+                               float *grid, float *weights, int *indexes,
+                               void *stream);
 int sn_gridding_backward(const float *grad_grid, const float *weights,
                          const int *indexes, int b, int npts, int nverts,
                          float *grad_ptcloud, void *stream);

@@ -30,12 +30,18 @@ __global__ __launch_bounds__(256) void gridding_fwd_kernel(int npts, int s, int 
                                                            const float *__restrict__ ptcloud,
                                                            float *__restrict__ grid,
                                                            float *__restrict__ weights,
-                                                           int *__restrict__ indexes, long total) {
+                                                           int *__restrict__ indexes, long total,
+                                                           int skip_zero_rows) {
   const int len = 2 * s;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
     const long b = e / npts;
     const float px = ptcloud[e * 3 + 0], py = ptcloud[e * 3 + 1], pz = ptcloud[e * 3 + 2];
+    if (skip_zero_rows && (px + py) + pz == 0.f) {  // padding row (cuda/gridding/__init__.py:43-46)
+      for (int c = 0; c < 24; ++c) weights[e * 24 + c] = 0.f;
+      for (int c = 0; c < 8; ++c) indexes[e * 8 + c] = -1;
+      continue;
+    }
     int lx, ux, ly, uy, lz, uz;
     corners(px, lx, ux);
     corners(py, ly, uy);
@@ -274,8 +280,25 @@ extern "C" int sn_gridding_forward(const float *ptcloud, int b, int npts, int sc
   const long total = (long)b * npts;
   if (total > 0)
     gridding_fwd_kernel<<<lin_blocks(total), 256, 0, st>>>(npts, s, nverts, ptcloud, grid, weights,
-                                                           indexes, total);
+                                                           indexes, total, 0);
   return sn::launch_status("sn_gridding_forward");
+}
+
+extern "C" int sn_gridding_forward_padded(const float *ptcloud, int b, int npts, int scale,
+                                          float *grid, float *weights, int *indexes, void *stream) {
+  SN_REQUIRE(grid, "sn_gridding_forward_padded: null pointer");
+  SN_REQUIRE(b >= 1 && npts >= 0 && scale >= 2 && scale % 2 == 0 && scale <= 1024,
+             "sn_gridding_forward_padded: bad sizes");
+  const int s = scale / 2, nverts = 8 * s * s * s;
+  hipStream_t st = sn::as_stream(stream);
+  SN_HIP(hipMemsetAsync(grid, 0, (size_t)b * nverts * 4, st));
+  const long total = (long)b * npts;
+  if (total > 0) {
+    SN_REQUIRE(ptcloud && weights && indexes, "sn_gridding_forward_padded: null pointer");
+    gridding_fwd_kernel<<<lin_blocks(total), 256, 0, st>>>(npts, s, nverts, ptcloud, grid, weights,
+                                                           indexes, total, 1);
+  }
+  return sn::launch_status("sn_gridding_forward_padded");
 }
 
 extern "C" int sn_gridding_dist_forward(const float *ptcloud, int b, int npts, int min_x, int max_x,

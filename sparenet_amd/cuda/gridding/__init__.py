@@ -12,10 +12,12 @@ from sparenet_amd import _lib
 
 
 class GriddingFunction(torch.autograd.Function):
-    """scale here is the HALF scale the reference passes (bounds [-scale, scale-1])."""
+    """scale here is the HALF scale the reference passes (bounds [-scale, scale-1]).  With
+    skip_padding the rows whose coordinates sum to zero contribute nothing (zero gradient): the
+    module's padding rule, applied in the kernel."""
 
     @staticmethod
-    def forward(ctx, scale, ptcloud):
+    def forward(ctx, scale, ptcloud, skip_padding=False):
         ptcloud = ptcloud.contiguous().float()
         b, n, _ = ptcloud.shape
         full = 2 * int(scale)
@@ -24,7 +26,8 @@ class GriddingFunction(torch.autograd.Function):
         weights = torch.empty(b, n, 8, 3, device=dev)
         indexes = torch.empty(b, n, 8, dtype=torch.int32, device=dev)
         with torch.cuda.device_of(ptcloud):
-            code = _lib.lib().sn_gridding_forward(
+            fn = _lib.lib().sn_gridding_forward_padded if skip_padding else _lib.lib().sn_gridding_forward
+            code = fn(
                 _lib.fptr(ptcloud, "ptcloud"), b, n, full, _lib.fptr(grid, "grid"),
                 _lib.fptr(weights, "grid_pt_weights"), _lib.iptr(indexes, "grid_pt_indexes"),
                 _lib.stream_of(ptcloud))
@@ -44,24 +47,21 @@ class GriddingFunction(torch.autograd.Function):
                 _lib.iptr(indexes, "grid_pt_indexes"), b, n, grad_grid.size(1),
                 _lib.fptr(grad_ptcloud, "grad_ptcloud"), _lib.stream_of(grad_grid))
         _lib.check(code, "sn_gridding_backward")
-        return None, grad_ptcloud
+        return None, grad_ptcloud, None
 
 
 class Gridding(torch.nn.Module):
     """ptcloud [B,n,3] in [-1,1) -> occupancy grid [B, scale^3].  Rows whose coordinates sum
-    to zero are padding and are dropped per sample, so samples are gridded one by one."""
+    to zero are padding and are ignored (cuda/gridding/__init__.py:41-47)."""
 
     def __init__(self, scale=1):
         super().__init__()
         self.scale = scale // 2          # half extent: vertices span [-scale/2, scale/2 - 1]
 
     def forward(self, ptcloud):
-        half = self.scale
-        per_sample = []
-        for cloud in (ptcloud * half).unbind(dim=0):          # [n,3] each
-            real = cloud[cloud.sum(dim=1).ne(0)]              # zero rows = padding
-            per_sample.append(GriddingFunction.apply(half, real.unsqueeze(0)))
-        return torch.cat(per_sample, dim=0).contiguous()
+        # the reference grids sample by sample after dropping the zero (padding) rows on the host;
+        # the kernel applies the same rule per point, so the whole batch is one launch
+        return GriddingFunction.apply(self.scale, ptcloud * self.scale, True)
 
 
 class GriddingReverseFunction(torch.autograd.Function):
