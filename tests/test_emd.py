@@ -26,6 +26,14 @@ def _clouds(b, n, seed, kind="uniform"):
     elif kind == "lattice":
         x = torch.randint(0, 8, (b, n, 3), generator=g).float() / 7
         y = torch.randint(0, 8, (b, n, 3), generator=g).float() / 7
+    elif kind == "clustered":
+        c = torch.rand(b, 6, 3, generator=g)
+        pick = lambda: torch.gather(c, 1, torch.randint(0, 6, (b, n, 1), generator=g).expand(-1, -1, 3))
+        x = (pick() + 0.003 * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
+        y = (pick() + 0.003 * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
+    elif kind == "far":
+        x = x + 50.0
+        y = torch.rand(b, n, 3, generator=g) + 50.0
     else:
         y = torch.rand(b, n, 3, generator=g)
     return x.numpy(), y.numpy()
@@ -117,6 +125,10 @@ def test_hip_matches_golden(golden_dir, dev):
     (1, 3072, 4, 0.01, "lattice", 6),     # ties + two reference tiles of different delta
     (5, 1024, 1, 0.005, "uniform", 7),
     (1, 1024, 0, 0.005, "uniform", 8),    # iters = 0
+    (9, 1024, 20, 0.005, "uniform", 9),   # batch not a multiple of 8 (XCD map), tail iterations
+    (2, 2048, 10, -0.001, "uniform", 10), # negative eps: prices may fall (price floor of the filter)
+    (1, 8192, 6, 0.005, "clustered", 11), # tight clusters: long hit queues, many exact batches
+    (2, 1024, 8, 0.005, "far", 12),       # large offsets: |t|^2 - 2 t.x cancels heavily
 ])
 def test_hip_matches_oracle(b, n, iters, eps, kind, seed, dev):
     x, y = _clouds(b, n, seed, kind)
