@@ -322,6 +322,12 @@ __host__ __device__ inline int bid_split(int ngroups, int G) {
 
 __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const Top2 &top,
                                          float eps) {
+  if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
+    A.bid[o + j] = -1;
+    A.bid2[o + j] = -1;
+    A.bid_inc[o + j] = 0.f;
+    return;
+  }
   const float inc = (top.best - top.better) + eps;
   A.bid[o + j] = top.best_i;
   A.bid2[o + j] = top.better_i == top.best_i ? -1 : top.better_i;
@@ -678,6 +684,7 @@ __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
     const int j = list[(size_t)b * n + u];
     const int tgt = bid[(size_t)b * n + j];
+    if (tgt < 0) continue;  // no bid (non-finite input)
     const float bi = bid_inc[(size_t)b * n + j];
     const float mi = max_inc[(size_t)b * n + tgt];
     if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
@@ -697,6 +704,10 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
     const int j = list[o + u];
     const int tgt = bid[o + j];
+    if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
+      if (!last) flags[o + rank1[o + j]] = 1;
+      continue;
+    }
     if (last || max_idx[o + tgt] == j) {
       const int inv = assignment_inv[o + tgt];
       if (!last && inv != -1) {
@@ -790,7 +801,12 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
     const long bb = e / n;
-    const float *a = xyz1 + e * 3, *o = xyz2 + (bb * n + assignment[e]) * 3;
+    const int k = assignment[e];
+    if (k < 0) {  // unassigned (iters == 0 or non-finite input)
+      grad[e * 3 + 0] = grad[e * 3 + 1] = grad[e * 3 + 2] = 0.f;
+      continue;
+    }
+    const float *a = xyz1 + e * 3, *o = xyz2 + (bb * n + k) * 3;
     const float g = graddist[e] * 2;
     grad[e * 3 + 0] = g * (a[0] - o[0]);
     grad[e * 3 + 1] = g * (a[1] - o[1]);
