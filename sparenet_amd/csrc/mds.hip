@@ -265,9 +265,48 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
       bhx = hx, bhy = hy, bhz = hz;
     }
   }
-  // a pick whose squared distance to the box reaches this adds exactly 0 to every point of the
-  // slot (the margin covers the rounding of the test and of the d computed in the update)
+  // Slot summaries, kept by lane i for slot i and refreshed whenever the slot is updated:
+  //   sval / slow / sx / sown  -- the slot's smallest key (density bits, low), its x and its lane
+  //   reach2                   -- squared distance up to which a pick can still CHANGE the slot.
+  // (1) exp(-d/t) is exactly 0 beyond d = 104 t.  (2) An increment below half an ulp of the
+  // density it is added to leaves the density unchanged: with vmin the smallest density of the
+  // slot, every v >= vmin has ulp(v) / 2 >= vmin 2^-25, and an increment is at most
+  // 2 exp(-gap^2 / t) (1 + 2^-21) for a pick at squared distance >= gap^2 from the slot's box; so
+  // beyond gap^2 = t (ln 2^26 - ln vmin) the update is a no-op for the whole slot.  Late in the
+  // run (every region already holds picks) this is a ~3x smaller ball than (1).
   const float far2 = cut2 * 1.001f;
+  unsigned sval = 0xffffffffu, slow = 0xffffffffu;
+  float sx = 0.f, reach2 = -1.f;
+  int sown = 0;
+  auto summarize = [&](int i, unsigned tv, unsigned lw, float x) {  // i: static slot index
+    const unsigned sm = wave_min_u32(tv);
+    unsigned long long eq = __ballot(tv == sm);
+    if (__popcll(eq) > 1) {  // equal densities inside the slot: the smaller low wins
+      const unsigned cand = tv == sm ? lw : 0xffffffffu;
+      eq = __ballot(cand == wave_min_u32(cand));
+    }
+    const int own = (int)__builtin_ctzll(eq);
+    const unsigned o_low = (unsigned)__builtin_amdgcn_readlane((int)lw, own);
+    const float o_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), own));
+    const float vmin = __uint_as_float(sm);
+    // t ((ln 2^26 - ln vmin) (1 + 1e-3) + 0.01): the margins cover v_log_f32, the rounding of the
+    // box test and of d, and sn_expf's <= 2 ulp
+    float r2 = far2;
+    if (vmin > 1e-30f) {
+      const float lg = 18.0219f - 0.693147182f * __builtin_amdgcn_logf(vmin);
+      r2 = __builtin_fminf(far2, __builtin_fmaxf(t * (lg * 1.001f + 0.01f), 0.f));
+    }
+    if (lane == i) {
+      sval = sm;
+      slow = o_low;
+      sx = o_x;
+      sown = own;
+      reach2 = (blx <= bhx) ? r2 : -1.f;  // empty slot: never near
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) summarize(i, __float_as_uint(tmp[i]), low[i], px[i]);
+
   int last = 0;
   if (tid == 0) out[0] = 0;
   // The pick's coordinates travel with the arg-min through LDS (a global read of xyz[last] at
@@ -279,13 +318,104 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
   float x1 = x0, y1 = y0, z1 = z0;
   unsigned last_low = 0;  // low bits of point 0
 
+  // Two round loops.  When the cut radius covers most of the cloud (dense regime: t large against
+  // the cloud's extent) nearly every slot is updated in every round; summaries per updated slot
+  // then cost more than one scan of all slots, and the absorption bound excludes little.
+  if (cut2 > 0.5f * diag2) {
+    for (int j = 1; j < m; ++j) {
+      // which slots of this wave can receive a non-zero update?
+      const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
+      const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
+      const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
+      const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
+      unsigned mn = 0xffffffffu;  // densities are >= 0: their bit patterns order like the floats
+  #pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        if ((mask >> i) & 1u) {  // wave-uniform
+          const float v = (low[i] == last_low) ? 1e9f : tmp[i];
+          const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
+          const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
+          // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
+          tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
+        }
+        mn = umin32(mn, __float_as_uint(tmp[i]));
+      }
+      // Arg-min of (density, bitrev, k) inside the wave.  Common case: the minimum density is
+      // held by exactly one entry, found with one compare per slot; exact ties take the full
+      // key comparison.
+      const unsigned wm = wave_min_u32(mn);
+      int hits = 0, istar = 0;  // scalar: number of entries equal to wm, and their slot
+  #pragma unroll
+      for (int i = 0; i < PPT; ++i) {
+        const int c = __popcll(__ballot(__float_as_uint(tmp[i]) == wm));
+        hits += c;
+        istar += i * c;
+      }
+      unsigned wl = 0xffffffffu;
+      float wx = 0.f;
+      int wi = 0;
+      bool winner;
+      if (hits == 1) {
+        winner = mn == wm;
+        wi = istar;
+  #pragma unroll
+        for (int i = 0; i < PPT; ++i)
+          if (i == istar) {  // wave-uniform pick of a statically indexed register
+            asm volatile("");
+            wl = low[i];
+            wx = px[i];
+          }
+      } else {
+  #pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+          const bool lt = __float_as_uint(tmp[i]) == wm && low[i] < wl;
+          wl = lt ? low[i] : wl;
+          wx = lt ? px[i] : wx;
+          wi = lt ? i : wi;
+        }
+        const unsigned wlmin = wave_min_u32(wl);
+        winner = wl == wlmin && wl != 0xffffffffu;  // lows of real points are unique
+      }
+      const int buf = j & 1;
+      if (lane == 0) wave_val[buf][wave] = wm;
+      if (winner) {
+        const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
+        wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
+      }
+      __syncthreads();
+      // every wave reduces the 16 hand-offs in its own registers
+      const int l16 = lane & 15;
+      const unsigned v16 = wave_val[buf][l16];
+      const float4 pk = wave_pick[buf][l16];
+      const unsigned minv = row_min_u32(v16);
+      const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
+      const unsigned minl = row_min_u32(lw);
+      const int wsel = (int)__builtin_ctzll(__ballot(lw == minl));
+      if (__builtin_amdgcn_readfirstlane((int)minv) >= (int)kBig) {
+        last = 0;  // nothing below 1e9: the reference's threads all report (1e9, index 0)
+        last_low = 0;
+        x1 = x0;
+        y1 = y0;
+        z1 = z0;
+      } else {
+        last_low = (unsigned)__builtin_amdgcn_readlane((int)lw, wsel);
+        last = (int)((last_low >> 1) & 0x7fffu);
+        x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.x), wsel));
+        y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.y), wsel));
+        z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.z), wsel));
+      }
+      if (tid == 0) out[j] = last;
+    }
+    return;
+  }
   for (int j = 1; j < m; ++j) {
-    // which slots of this wave can receive a non-zero update?
+    // which slots of this wave can the pick still change?
     const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
     const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
     const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
-    const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
-    unsigned mn = 0xffffffffu;  // densities are >= 0: their bit patterns order like the floats
+    const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < reach2);
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       if ((mask >> i) & 1u) {  // wave-uniform
@@ -296,49 +426,24 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
         const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
         // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
         tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
+        summarize(i, __float_as_uint(tmp[i]), low[i], px[i]);
       }
-      mn = umin32(mn, __float_as_uint(tmp[i]));
     }
-    // Arg-min of (density, bitrev, k) inside the wave.  Common case: the minimum density is
-    // held by exactly one entry, found with one compare per slot; exact ties take the full
-    // key comparison.
-    const unsigned wm = wave_min_u32(mn);
-    int hits = 0, istar = 0;  // scalar: number of entries equal to wm, and their slot
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      const int c = __popcll(__ballot(__float_as_uint(tmp[i]) == wm));
-      hits += c;
-      istar += i * c;
+    // Arg-min of (density, bitrev, k) inside the wave = the smallest slot summary.
+    const unsigned wm = wave_min_u32(sval);  // lanes >= PPT hold ~0
+    unsigned long long eq = __ballot(sval == wm);
+    if (__popcll(eq) > 1) {  // equal densities in several slots: the smaller low wins
+      const unsigned cand = sval == wm ? slow : 0xffffffffu;
+      eq = __ballot(cand == wave_min_u32(cand));
     }
-    unsigned wl = 0xffffffffu;
-    float wx = 0.f;
-    int wi = 0;
-    bool winner;
-    if (hits == 1) {
-      winner = mn == wm;
-      wi = istar;
-#pragma unroll
-      for (int i = 0; i < PPT; ++i)
-        if (i == istar) {  // wave-uniform pick of a statically indexed register
-          asm volatile("");
-          wl = low[i];
-          wx = px[i];
-        }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PPT; ++i) {
-        const bool lt = __float_as_uint(tmp[i]) == wm && low[i] < wl;
-        wl = lt ? low[i] : wl;
-        wx = lt ? px[i] : wx;
-        wi = lt ? i : wi;
-      }
-      const unsigned wlmin = wave_min_u32(wl);
-      winner = wl == wlmin && wl != 0xffffffffu;  // lows of real points are unique
-    }
+    const int istar = (int)__builtin_ctzll(eq);
+    const unsigned wl = (unsigned)__builtin_amdgcn_readlane((int)slow, istar);
+    const int wo = __builtin_amdgcn_readlane(sown, istar);
     const int buf = j & 1;
-    if (lane == 0) wave_val[buf][wave] = wm;
-    if (winner) {
-      const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
+    if (lane == 0) {
+      const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), istar));
+      const float2 q = reinterpret_cast<const float2 *>(yz)[istar * 1024 + wave * 64 + wo];
+      wave_val[buf][wave] = wm;
       wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
     }
     __syncthreads();
