@@ -249,6 +249,15 @@ def other_ops(dev, pred, mean_mst):
     def cubic_fb():
         cubic(q, feats).sum().backward()
     out["cubic_sampling_2048x32c_fwd_bwd"] = ms(cubic_fb)
+    # EdgeConv graph of the generator (models/sparenet_generator.py:192-209): 3000 input points, k = 8
+    from sparenet_amd.cuda.knn import get_graph_feature, knn
+    xf = torch.rand(B, 256, 3000, generator=g).to(dev).requires_grad_(True)
+    out["knn_k8_c256_n3000"] = ms(lambda: knn(xf.detach(), 8))
+    nbr = knn(xf.detach(), 8)
+
+    def graph_fb():
+        get_graph_feature(xf, k=8, idx=nbr).sum().backward()
+    out["graph_feature_c256_fwd_bwd"] = ms(graph_fb)
     return out
 
 

@@ -204,6 +204,21 @@ int sn_p2i_sum_backward(const float *out_grad, const float *points,
                         int channels, int batch, int h, int w, float radius,
                         float *points_grad, float *feat_grad, void *stream);
 
+/* ---------------------------------------------------------- EdgeConv k-NN graph
+ * replaces knn() / get_graph_feature() of models/sparenet_generator.py:852-906 (GPU branch:
+ * the un-vendored KNN_CUDA 0.2 wheel).  inner[b,n,n] = x^T x (a plain batched GEMM, computed
+ * by the caller with rocBLAS / torch.bmm), xx[b,n] = |x_j|^2.  idx[b,n,k] (int64): the k
+ * smallest  |x_j|^2 - 2 x_i.x_j  per row, ascending, equal scores by lower index (the point
+ * itself comes first); k in {1, 2, 4, 8, 16, 20, 32}. */
+int sn_knn_topk(const float *inner, const float *xx, int b, int n, int k,
+                long long *idx, void *stream);
+/* x[b,c,n], idx[b,n,k] -> out[b,2c,n,k]: out[:, ch] = x[idx] - x, out[:, c + ch] = x
+ * (cat((feature - x, x), dim=3).permute(0, 3, 1, 2), :899-905); backward: grad_x[b,c,n]. */
+int sn_graph_feature_forward(const float *x, const long long *idx, int b, int c,
+                             int n, int k, float *out, void *stream);
+int sn_graph_feature_backward(const float *grad_out, const long long *idx, int b,
+                              int c, int n, int k, float *grad_x, void *stream);
+
 /* ------------------------------------------------------- depth-map projection
  * The per-view glue of ComputeDepthMaps.forward (utils/p2i_utils.py:211-228 and the NDC ->
  * pixel rescale of cuda/p2i_op/__init__.py:117-121) fused into two small kernels each way:

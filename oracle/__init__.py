@@ -298,3 +298,24 @@ def cubic_backward(grad_out, idx, c, scale, ns):
     out = np.zeros((b, c, scale, scale, scale), np.float32)
     lib().oracle_cubic_backward(pg, pi, b, n, c, scale, int(ns), _pf(out))
     return out
+
+
+# -------------------------------------------------------------------- k-NN graph (numpy only)
+def knn(x, k):
+    """x [B,C,N] -> idx [B,N,k]: the reference's ranking  |x_j|^2 - 2 x_i.x_j  (the CPU branch of
+    models/sparenet_generator.py:872-875 up to the row constant) in float64, ascending, equal scores by
+    lower index."""
+    x = np.asarray(x, np.float64)
+    inner = np.einsum("bci,bcj->bij", x, x)
+    score = (x * x).sum(1)[:, None, :] - 2.0 * inner
+    return np.argsort(score, axis=2, kind="stable")[:, :, :k]
+
+
+def graph_feature(x, idx):
+    """x [B,C,N], idx [B,N,k] -> [B,2C,N,k] (models/sparenet_generator.py:880-906)."""
+    x = np.asarray(x, np.float32)
+    b, c, n = x.shape
+    k = idx.shape[2]
+    nb = np.take_along_axis(x[:, :, None, :].repeat(n, 2), idx[:, None, :, :].repeat(c, 1), axis=3)
+    own = x[:, :, :, None].repeat(k, 3)
+    return np.concatenate([nb - own, own], axis=1)

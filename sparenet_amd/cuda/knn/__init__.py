@@ -1,0 +1,72 @@
+"""EdgeConv's k-NN graph in feature space -- host-side mirror of knn() and get_graph_feature()
+(models/sparenet_generator.py:852-877, :880-906), backed by sn_knn_topk and
+sn_graph_feature_forward / backward (include/sparenet_hip.h).
+
+The reference's GPU branch calls the un-vendored KNN_CUDA wheel; its CPU branch ranks
+-|x_i|^2 + 2 x_i.x_j - |x_j|^2 with topk.  Here the inner products are one batched GEMM
+(torch.bmm = rocBLAS) and the ranking is a HIP kernel; neighbours come out ascending by distance, the
+point itself first, equal scores by lower index.
+"""
+import ctypes
+
+import torch
+
+from sparenet_amd import _lib
+
+
+def knn(x, k: int):
+    """x [B, C, N] float32 on the GPU -> idx [B, N, k] int64 (indices of the k nearest points)."""
+    if x.dim() != 3:
+        raise ValueError("knn expects x [batch, feature_dim, num_points]")
+    x = x.contiguous().float()
+    b, _, n = x.shape
+    inner = torch.bmm(x.transpose(2, 1), x).contiguous()        # [B, N, N]
+    xx = (x * x).sum(dim=1).contiguous()                        # [B, N]
+    idx = torch.empty(b, n, k, dtype=torch.int64, device=x.device)
+    with torch.cuda.device_of(x):
+        code = _lib.lib().sn_knn_topk(_lib.fptr(inner, "inner"), _lib.fptr(xx, "xx"), b, n, int(k),
+                                      ctypes.c_void_p(idx.data_ptr()), _lib.stream_of(x))
+    _lib.check(code, "sn_knn_topk")
+    return idx
+
+
+class GraphFeatureFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx):
+        x = x.contiguous().float()
+        idx = idx.contiguous()
+        b, c, n = x.shape
+        k = idx.size(2)
+        out = torch.empty(b, 2 * c, n, k, device=x.device)
+        with torch.cuda.device_of(x):
+            code = _lib.lib().sn_graph_feature_forward(
+                _lib.fptr(x, "x"), ctypes.c_void_p(idx.data_ptr()), b, c, n, k, _lib.fptr(out, "out"),
+                _lib.stream_of(x))
+        _lib.check(code, "sn_graph_feature_forward")
+        ctx.save_for_backward(idx)
+        ctx.shape = (b, c, n, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        b, c, n, k = ctx.shape
+        grad_out = grad_out.contiguous().float()
+        grad_x = torch.empty(b, c, n, device=grad_out.device)
+        with torch.cuda.device_of(grad_out):
+            code = _lib.lib().sn_graph_feature_backward(
+                _lib.fptr(grad_out, "grad_out"), ctypes.c_void_p(idx.data_ptr()), b, c, n, k,
+                _lib.fptr(grad_x, "grad_x"), _lib.stream_of(grad_out))
+        _lib.check(code, "sn_graph_feature_backward")
+        return grad_x, None
+
+
+def get_graph_feature(x, k: int = 20, idx=None):
+    """x [B, C, N] -> edge features [B, 2C, N, k]: (neighbour - point, point) per neighbour."""
+    batch_size, num_points = x.size(0), x.size(2)
+    x = x.view(batch_size, -1, num_points)
+    if idx is None:
+        idx = knn(x, k=k)
+    if idx.dtype != torch.int64:
+        idx = idx.long()
+    return GraphFeatureFunction.apply(x, idx)
