@@ -216,8 +216,10 @@ int sn_knn_topk(const float *inner, const float *xx, int b, int n, int k,
  * (cat((feature - x, x), dim=3).permute(0, 3, 1, 2), :899-905); backward: grad_x[b,c,n]. */
 int sn_graph_feature_forward(const float *x, const long long *idx, int b, int c,
                              int n, int k, float *out, void *stream);
+size_t sn_graph_feature_backward_workspace_bytes(int b, int n, int k);
 int sn_graph_feature_backward(const float *grad_out, const long long *idx, int b,
-                              int c, int n, int k, float *grad_x, void *stream);
+                              int c, int n, int k, float *grad_x, void *workspace,
+                              size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------- depth-map projection
  * The per-view glue of ComputeDepthMaps.forward (utils/p2i_utils.py:211-228 and the NDC ->

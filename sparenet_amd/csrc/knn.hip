@@ -99,26 +99,75 @@ __global__ __launch_bounds__(256) void graph_feature_fwd_kernel(const float *__r
   }
 }
 
+// Backward without floating-point atomics: the graph is the same for all channels, so the edges
+// are first inverted once (for every point q the list of edges (p, j) with idx[p, j] == q: count,
+// scan, fill), then one thread per (b, ch, q) adds its own terms and the terms of its incoming edges.
+__global__ __launch_bounds__(256) void graph_count_kernel(const long long *__restrict__ idx, int n,
+                                                          int k, long edges, int *__restrict__ cnt) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < edges; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / ((long)n * k);
+    atomicAdd(&cnt[b * n + idx[e]], 1);
+  }
+}
+
+// per cloud: in-place exclusive scan of the n counts
+__global__ __launch_bounds__(1024) void graph_scan_kernel(int *__restrict__ cnt, int n) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  int *c = cnt + (size_t)blockIdx.x * n;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? c[i] : 0;
+    int incl = v;
+    for (int m = 1; m < 64; m <<= 1) {
+      const int u = __shfl_up(incl, m);
+      if ((tid & 63) >= m) incl += u;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+    if (i < n) c[i] = pre + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+}
+
+// elist[b][start(q) ...] = edge ids p * k + j; afterwards offs[b][q] is the END of q's list
+__global__ __launch_bounds__(256) void graph_fill_kernel(const long long *__restrict__ idx, int n, int k,
+                                                         long edges, int *__restrict__ offs,
+                                                         int *__restrict__ elist) {
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < edges; e += (long)gridDim.x * blockDim.x) {
+    const long b = e / ((long)n * k);
+    const int local = (int)(e - b * n * k);
+    const int pos = atomicAdd(&offs[b * n + idx[e]], 1);
+    elist[b * (long)n * k + pos] = local;
+  }
+}
+
 __global__ __launch_bounds__(256) void graph_feature_bwd_kernel(const float *__restrict__ g,
-                                                                const long long *__restrict__ idx,
-                                                                int c, int n, int k, long total,
+                                                                const int *__restrict__ offs,
+                                                                const int *__restrict__ elist, int c,
+                                                                int n, int k, long total,
                                                                 float *__restrict__ gx) {
-  // one thread per (b, ch, n): its own terms by a plain sum, the neighbour terms by atomics
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
-    const int p = (int)(e % n);
+    const int q = (int)(e % n);
     const long t = e / n;
     const int ch = (int)(t % c);
     const long b = t / c;
-    const float *g1 = g + ((b * 2 * c + ch) * n + p) * k;
-    const float *g2 = g + ((b * 2 * c + c + ch) * n + p) * k;
-    float own = 0.f;
-    float *gb = gx + (b * c + ch) * n;
-    for (int j = 0; j < k; ++j) {
-      own += g2[j] - g1[j];
-      unsafeAtomicAdd(gb + idx[(b * n + p) * k + j], g1[j]);
-    }
-    unsafeAtomicAdd(gb + p, own);
+    const float *g1 = g + (b * 2 * c + ch) * (long)n * k;       // d out / d (neighbour - point)
+    const float *g2 = g + (b * 2 * c + c + ch) * (long)n * k;   // d out / d point
+    float acc = 0.f;
+    for (int j = 0; j < k; ++j) acc += g2[(long)q * k + j] - g1[(long)q * k + j];
+    const int beg = q > 0 ? offs[b * n + q - 1] : 0, end = offs[b * n + q];
+    const int *el = elist + b * (long)n * k;
+    for (int i = beg; i < end; ++i) acc += g1[el[i]];
+    gx[e] = acc;
   }
 }
 
@@ -161,13 +210,27 @@ extern "C" int sn_graph_feature_forward(const float *x, const long long *idx, in
   return sn::launch_status("sn_graph_feature_forward");
 }
 
+extern "C" size_t sn_graph_feature_backward_workspace_bytes(int b, int n, int k) {
+  if (b < 1 || n < 1 || k < 1) return 0;
+  return sn::align_up((size_t)b * n * 4, 256) + (size_t)b * n * k * 4;
+}
+
 extern "C" int sn_graph_feature_backward(const float *grad_out, const long long *idx, int b, int c,
-                                         int n, int k, float *grad_x, void *stream) {
-  SN_REQUIRE(grad_out && idx && grad_x, "sn_graph_feature_backward: null pointer");
+                                         int n, int k, float *grad_x, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(grad_out && idx && grad_x && workspace, "sn_graph_feature_backward: null pointer");
   SN_REQUIRE(b >= 1 && c >= 1 && n >= 1 && k >= 1, "sn_graph_feature_backward: bad sizes");
+  SN_REQUIRE(workspace_bytes >= sn_graph_feature_backward_workspace_bytes(b, n, k),
+             "sn_graph_feature_backward: workspace too small");
   hipStream_t s = sn::as_stream(stream);
-  SN_HIP(hipMemsetAsync(grad_x, 0, (size_t)b * c * n * 4, s));
+  int *offs = static_cast<int *>(workspace);
+  int *elist = reinterpret_cast<int *>(static_cast<char *>(workspace) + sn::align_up((size_t)b * n * 4, 256));
+  const long edges = (long)b * n * k;
+  SN_HIP(hipMemsetAsync(offs, 0, (size_t)b * n * 4, s));
+  graph_count_kernel<<<blocks_for(edges), 256, 0, s>>>(idx, n, k, edges, offs);
+  graph_scan_kernel<<<b, 1024, 0, s>>>(offs, n);
+  graph_fill_kernel<<<blocks_for(edges), 256, 0, s>>>(idx, n, k, edges, offs, elist);
   const long total = (long)b * c * n;
-  graph_feature_bwd_kernel<<<blocks_for(total), 256, 0, s>>>(grad_out, idx, c, n, k, total, grad_x);
+  graph_feature_bwd_kernel<<<blocks_for(total), 256, 0, s>>>(grad_out, offs, elist, c, n, k, total, grad_x);
   return sn::launch_status("sn_graph_feature_backward");
 }

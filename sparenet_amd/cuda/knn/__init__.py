@@ -54,9 +54,12 @@ class GraphFeatureFunction(torch.autograd.Function):
         grad_out = grad_out.contiguous().float()
         grad_x = torch.empty(b, c, n, device=grad_out.device)
         with torch.cuda.device_of(grad_out):
+            nbytes = _lib.lib().sn_graph_feature_backward_workspace_bytes(b, n, k)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=grad_out.device)
             code = _lib.lib().sn_graph_feature_backward(
                 _lib.fptr(grad_out, "grad_out"), ctypes.c_void_p(idx.data_ptr()), b, c, n, k,
-                _lib.fptr(grad_x, "grad_x"), _lib.stream_of(grad_out))
+                _lib.fptr(grad_x, "grad_x"), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes),
+                _lib.stream_of(grad_out))
         _lib.check(code, "sn_graph_feature_backward")
         return grad_x, None
 
