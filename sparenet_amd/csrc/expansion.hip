@@ -22,14 +22,36 @@ namespace {
 
 constexpr int kPMax = 512;
 
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
+
+// wave-uniform minimum over the 64 lanes: four DPP steps inside each row of 16, then 4 readlanes
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));  // row_mirror
+  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+  return umin32(umin32(a, b), umin32(c, d));
+}
+
+// A vertex that is in the tree (or a padding slot) carries this key: as a SIGNED int it is below every
+// squared length, so the relaxation test never fires; as an UNSIGNED int it is above every squared
+// length, so the arg-min never returns it.
+constexpr unsigned kInTree = 0x80000000u;
+// rn(sqrt(a)) == rn(sqrt(b)) with a < b needs b - a <= 4 ulp(a): sqrt(b) - sqrt(a) <= ulp(s) <= 2^-23 s,
+// times sqrt(a) + sqrt(b) <= 2 sqrt(b), is <= 2^-22 b, and ulp(a) > 2^-24 a.  Twice that is the
+// window inside which a decision on squared lengths is re-taken on the rounded square roots.
+constexpr unsigned kSqrtTieUlps = 8u;
+
 template <int PPL>
 __global__ __launch_bounds__(64) void expansion_fwd_kernel(
     int n, int P, const float *__restrict__ xyz, float alpha, float *__restrict__ dist,
     int *__restrict__ assignment, float *__restrict__ patch_mean) {
 #pragma clang fp contract(off)
   __shared__ float4 pts[kPMax];
-  __shared__ int s_parent[kPMax];
-  __shared__ float s_w[kPMax];
   __shared__ int s_cnt[kPMax];
   __shared__ float s_dist[kPMax];
   __shared__ int s_assign[kPMax];
@@ -41,89 +63,133 @@ __global__ __launch_bounds__(64) void expansion_fwd_kernel(
 
   for (int v = lane; v < P; v += 64) {
     pts[v] = make_float4(src[v * 3 + 0], src[v * 3 + 1], src[v * 3 + 2], 0.f);
-    s_parent[v] = -1;
-    s_w[v] = 0.f;
     s_cnt[v] = 0;
     s_dist[v] = 0.f;
     s_assign[v] = -1;
   }
   __syncthreads();
 
+  // Prim on SQUARED lengths held as their bit patterns (monotone for non-negative floats).  The
+  // reference orders by sqrtf(d2); rn(sqrt) is monotone, so a decision taken on d2 is the reference's
+  // decision unless the two d2 are within kSqrtTieUlps of each other -- those rounds (exact ties on
+  // lattice data, one in ~1e4 rounds on random data) are re-decided on the square roots themselves.
+  constexpr int NP = (PPL + 1) / 2;
   const bool lane_on = lane < L;
-  float px[PPL], py[PPL], pz[PPL], cur_dis[PPL];
-  int cur_idx[PPL];
-  unsigned vis = 0;
+  f2 px[NP], py[NP], pz[NP];
+  unsigned key[2 * NP];
+  int par[2 * NP];
 #pragma unroll
-  for (int r = 0; r < PPL; ++r) {
-    const int v = lane_on ? lane * PPL + r : 0;
-    const float4 q = pts[v];
-    px[r] = q.x;
-    py[r] = q.y;
-    pz[r] = q.z;
-    cur_dis[r] = 1e9f;
-    cur_idx[r] = 0;
+  for (int i = 0; i < NP; ++i) {
+    const int v0 = lane_on ? lane * PPL + 2 * i : 0, v1 = (lane_on && 2 * i + 1 < PPL) ? v0 + 1 : v0;
+    const float4 q0 = pts[v0], q1 = pts[v1];
+    px[i] = f2{q0.x, q1.x};
+    py[i] = f2{q0.y, q1.y};
+    pz[i] = f2{q0.z, q1.z};
+    key[2 * i] = lane_on ? __float_as_uint(1e18f) : kInTree;
+    key[2 * i + 1] = (lane_on && 2 * i + 1 < PPL) ? __float_as_uint(1e18f) : kInTree;
+    par[2 * i] = par[2 * i + 1] = 0;
   }
-  if (!lane_on) vis = 0xffffffffu;
-  if (lane == 0) vis |= 1u;
+  if (lane == 0) key[0] = kInTree;
   int last = 0;
 
-  // ---- Prim: P-1 rounds, no barrier
   for (int round = 0; round < P - 1; ++round) {
     const float4 ql = pts[last];  // wave-uniform LDS read
-    float bd = 1e9f;
-    int bv = lane_on ? lane * PPL : -1;  // visited / idle lanes carry (1e9, their slot)
-    if (!lane_on) bv = -1;
+    const f2 qx = f2{ql.x, ql.x}, qy = f2{ql.y, ql.y}, qz = f2{ql.z, ql.z};
+    unsigned d2[2 * NP], t[2 * NP], nearest = 0xffffffffu;
 #pragma unroll
-    for (int r = 0; r < PPL; ++r) {
-      const int v = lane * PPL + r;
-      float cand = 1e9f;
-      if (!((vis >> r) & 1u)) {
-        const float dx = px[r] - ql.x, dy = py[r] - ql.y, dz = pz[r] - ql.z;
-        const float d = __builtin_sqrtf((dx * dx + dy * dy) + dz * dz);
-        if (d < cur_dis[r]) {
-          cur_dis[r] = d;
-          cur_idx[r] = last;
+    for (int i = 0; i < NP; ++i) {
+      const f2 dx = px[i] - qx, dy = py[i] - qy, dz = pz[i] - qz;
+      const f2 d = (dx * dx + dy * dy) + dz * dz;
+      d2[2 * i] = __float_as_uint(d.x);
+      d2[2 * i + 1] = __float_as_uint(d.y);
+    }
+#pragma unroll
+    for (int r = 0; r < 2 * NP; ++r) {
+      t[r] = key[r] - d2[r];
+      nearest = umin32(nearest, t[r]);
+    }
+    if (__builtin_expect(__any(nearest <= kSqrtTieUlps), 0)) {
+#pragma unroll
+      for (int r = 0; r < 2 * NP; ++r) {
+        bool relax = (int)d2[r] < (int)key[r];
+        if (relax && t[r] <= kSqrtTieUlps)
+          relax = __builtin_sqrtf(__uint_as_float(d2[r])) < __builtin_sqrtf(__uint_as_float(key[r]));
+        key[r] = relax ? d2[r] : key[r];
+        par[r] = relax ? last : par[r];
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 2 * NP; ++r) {
+        const bool relax = (int)d2[r] < (int)key[r];
+        key[r] = relax ? d2[r] : key[r];
+        par[r] = relax ? last : par[r];
+      }
+    }
+
+    // next vertex: the smallest sqrt length, highest index among equals
+    unsigned lmin = key[0];
+#pragma unroll
+    for (int r = 1; r < 2 * NP; ++r) lmin = umin32(lmin, key[r]);
+    const unsigned thr = wave_min_u32(lmin) + kSqrtTieUlps;
+    unsigned long long hit[2 * NP], any = 0;
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < 2 * NP; ++r) {
+      hit[r] = __ballot(key[r] <= thr);
+      total += __popcll(hit[r]);
+      any |= hit[r];
+    }
+    if (__builtin_expect(total == 1, 1)) {
+      int mine = 0;
+#pragma unroll
+      for (int r = 0; r < 2 * NP; ++r) {
+        const bool h = key[r] <= thr;
+        mine = h ? lane * PPL + r : mine;
+        key[r] = h ? kInTree : key[r];
+      }
+      last = __builtin_amdgcn_readlane(mine, __builtin_ctzll(any));
+    } else {
+      float bd = 1e9f;
+      int bv = lane_on ? lane * PPL : -1;  // in-tree / idle lanes carry (1e9, their slot)
+#pragma unroll
+      for (int r = 0; r < PPL; ++r) {
+        const float cand = key[r] == kInTree ? 1e9f : __builtin_sqrtf(__uint_as_float(key[r]));
+        // ascending r with '<=' keeps the highest index among equal minima
+        if (lane_on && cand <= bd) {
+          bd = cand;
+          bv = lane * PPL + r;
         }
-        cand = cur_dis[r];
       }
-      // ascending r with '<=' keeps the highest index among equal minima
-      if (lane_on && cand <= bd) {
-        bd = cand;
-        bv = v;
-      }
-    }
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-      const float od = __shfl_xor(bd, m);
-      const int ov = __shfl_xor(bv, m);
-      const bool take = (od < bd) || (od == bd && ov > bv);
-      bd = take ? od : bd;
-      bv = take ? ov : bv;
-    }
-    last = bv;
-    const int owner = last / PPL, slot = last - owner * PPL;
-    if (lane == owner) {
+      for (int m = 1; m < 64; m <<= 1) {
+        const float od = __shfl_xor(bd, m);
+        const int ov = __shfl_xor(bv, m);
+        const bool take = (od < bd) || (od == bd && ov > bv);
+        bd = take ? od : bd;
+        bv = take ? ov : bv;
+      }
+      last = bv;
 #pragma unroll
       for (int r = 0; r < PPL; ++r)
-        if (r == slot) {
-          s_parent[last] = cur_idx[r];
-          s_w[last] = cur_dis[r];
-          vis |= 1u << r;
-        }
+        if (lane * PPL + r == last) key[r] = kInTree;
     }
   }
-  __syncthreads();
 
-  // ---- degrees, per-vertex parent edge back into registers
-  int par[PPL];
+  // ---- parent edge of every vertex (the root and anything never reached have none); the length is
+  // recomputed with the operands and the operation order of the relaxation that set the parent
   float wgt[PPL];
   unsigned alive = 0;
 #pragma unroll
   for (int r = 0; r < PPL; ++r) {
     const int v = lane * PPL + r;
-    par[r] = lane_on ? s_parent[v] : -1;
-    wgt[r] = lane_on ? s_w[v] : 0.f;
-    if (par[r] >= 0) {
+    const bool has = lane_on && v != 0 && key[r] == kInTree;
+    par[r] = has ? par[r] : -1;
+    const float4 q = pts[has ? par[r] : 0];
+    const float x = (r & 1) ? px[r / 2].y : px[r / 2].x, y = (r & 1) ? py[r / 2].y : py[r / 2].x,
+                z = (r & 1) ? pz[r / 2].y : pz[r / 2].x;
+    const float dx = x - q.x, dy = y - q.y, dz = z - q.z;
+    wgt[r] = has ? __builtin_sqrtf((dx * dx + dy * dy) + dz * dz) : 0.f;
+    if (has) {
       alive |= 1u << r;
       atomicAdd(&s_cnt[v], 1);
       atomicAdd(&s_cnt[par[r]], 1);

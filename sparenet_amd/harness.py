@@ -18,8 +18,18 @@ of the hot path appears where the reference calls it:
 
 It exists to measure what the ops cost inside the real step (MDS and the expansion penalty run inside the
 generator, not in the loss) and to exercise autograd through the whole chain.
+
+`GanStep` adds the adversarial half (runners/sparenet_gan_runner.py:69-113 train_step, :186-266 discriminator
+update, :268-347 generator update): the middle cloud, the ground truth and the partial input are rendered from
+all 8 views at one radius drawn from the list, the 8+8 maps go through a discriminator (here a bf16 stride-2
+conv surrogate with the reference's feature-map shapes), LSGAN targets, feature matching weighted by channel
+count, L1 image matching, and errG = 200 rec + 0.1 gan + fm + im (configs/base_config.py:67-73).
 """
+import random
+
 import torch
+
+from sparenet_amd.utils.p2i_utils import N_VIEWS_PREDEFINED, ComputeDepthMaps
 
 from sparenet_amd.cuda.chamfer_distance import ChamferDistance, ChamferDistanceMean
 from sparenet_amd.cuda.emd.emd_module import emdModule
@@ -93,3 +103,92 @@ class Completion(torch.nn.Module):
             dist1, _ = self.chamfer_dist(refine, gt)
             loss = loss + torch.mean(dist1).mean() * 0.5
         return loss, refine, middle, coarse, refine_loss, coarse_loss
+
+
+class SurrogateDiscriminator(torch.nn.Module):
+    """Shapes of PatchDiscriminator (models/sparenet_discriminator.py:13-81): [B,2V,S,S] -> validity [B,1]
+    and, with feat=True, the first four feature maps (16,32,64,128 channels at S/2..S/16).  Plain
+    stride-2 convolutions + LeakyReLU under bf16 autocast; no spectral norm, no batch norm."""
+
+    def __init__(self, img_shape=(2 * N_VIEWS_PREDEFINED, 256, 256)):
+        super().__init__()
+        widths = [img_shape[0], 16, 32, 64, 128, 256, 512]
+        self.blocks = torch.nn.ModuleList(
+            torch.nn.Conv2d(widths[i], widths[i + 1], 4, stride=2, padding=1) for i in range(6))
+        self.adv_layer = torch.nn.Conv2d(512, 1, 3, padding=1, bias=False)
+
+    def forward(self, img, feat=False, y=None):
+        feats, x = [], img
+        with torch.autocast(img.device.type, dtype=torch.bfloat16):
+            for conv in self.blocks:
+                x = torch.nn.functional.leaky_relu(conv(x), 0.2)
+                feats.append(x)
+            validity = self.adv_layer(x)
+        validity = validity.float().mean(dim=(2, 3)).view(img.shape[0], -1)
+        return (validity, [f.float() for f in feats[:4]]) if feat else validity
+
+
+class GanStep:
+    """One training step of SpareNetGANRunner on a generator with SpareNetGenerator's outputs."""
+
+    def __init__(self, generator, discriminator, completion, opt_g, opt_d, radius_list=(5.0, 7.0, 10.0),
+                 image_size=256, projection="orthorgonal", use_fm=True, use_im=True, weight_l2=200.0,
+                 weight_gan=0.1, weight_fm=1.0, weight_im=1.0, seed=0):
+        self.generator, self.discriminator, self.completion = generator, discriminator, completion
+        self.opt_g, self.opt_d = opt_g, opt_d
+        self.radius_list = list(radius_list)
+        self.use_fm, self.use_im = use_fm, use_im
+        self.weight_l2, self.weight_gan, self.weight_fm, self.weight_im = weight_l2, weight_gan, weight_fm, weight_im
+        self.renderer = ComputeDepthMaps(projection, 1.0, image_size)
+        self.criterion = torch.nn.MSELoss()
+        self.rng = random.Random(seed)
+
+    def _render_views(self, cloud, radius):
+        # [B, views, S, S]: one single-radius map per predefined view, concatenated on dim 1
+        return torch.cat([self.renderer(cloud, view_id=v, radius_list=[radius])
+                          for v in range(N_VIEWS_PREDEFINED)], dim=1)
+
+    def __call__(self, partial, gt):
+        batch = partial.shape[0]
+        real_label = torch.ones(batch, 1, device=partial.device)
+        fake_label = torch.zeros(batch, 1, device=partial.device)
+        self.renderer.to(partial.device)
+
+        rec_loss, _, middle, _, refine_loss, coarse_loss = self.completion(self.generator, partial, gt)
+
+        # ---- discriminator update (detached images)
+        self.opt_d.zero_grad()
+        radius = self.rng.sample(self.radius_list, 1)[0]
+        real_imgs = self._render_views(gt, radius)
+        fake_imgs = self._render_views(middle, radius)
+        input_imgs = self._render_views(partial, radius)
+        d_real = self.discriminator(torch.cat((input_imgs, real_imgs), dim=1).detach())
+        d_fake = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1).detach())
+        err_d_real, err_d_fake = self.criterion(d_real, real_label), self.criterion(d_fake, fake_label)
+        (err_d_real + err_d_fake).backward()
+        self.opt_d.step()
+
+        # ---- generator update: gradients reach the cloud through the renderer
+        self.opt_g.zero_grad()
+        loss_fm = loss_im = 0.0
+        if self.use_fm:
+            d_fake, fake_feats = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1), feat=True)
+            _, real_feats = self.discriminator(torch.cat((input_imgs, real_imgs), dim=1), feat=True)
+            maps = [f.shape[1] for f in fake_feats]
+            for f, r, c in zip(fake_feats, real_feats, maps):
+                loss_fm = loss_fm + float(c) / sum(maps) * torch.mean((f - r.detach()) ** 2)
+        else:
+            d_fake = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1))
+        err_g_d = self.criterion(d_fake, real_label)
+        if self.use_im:
+            loss_im = torch.nn.functional.l1_loss(fake_imgs, real_imgs.detach())
+        err_g = self.weight_l2 * rec_loss + self.weight_gan * err_g_d
+        if self.use_fm:
+            err_g = err_g + self.weight_fm * loss_fm
+        if self.use_im:
+            err_g = err_g + self.weight_im * loss_im
+        err_g.backward()
+        self.opt_g.step()
+        return dict(rec_loss=rec_loss.detach(), errG=err_g.detach(), errG_D=err_g_d.detach(),
+                    errD_real=err_d_real.detach(), errD_fake=err_d_fake.detach(),
+                    coarse_loss=coarse_loss.detach() * 1000, refine_loss=refine_loss.detach() * 1000)

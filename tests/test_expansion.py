@@ -98,11 +98,17 @@ def test_hip_matches_golden(golden_dir, dev):
     (2, 1024, 512, 1.5, "uniform"), (3, 768, 256, 1.5, "uniform"), (2, 512, 128, 1.0, "uniform"),
     (4, 256, 64, 1.5, "lattice"), (2, 128, 32, 1.5, "uniform"), (2, 64, 8, 0.5, "uniform"),
     (1, 8, 4, 1.5, "uniform"), (3, 6, 2, 1.5, "uniform"), (2, 1024, 512, 1.5, "lattice"),
+    (3, 1024, 512, 1.5, "jitter"), (2, 512, 256, 1.2, "jitter"), (2, 256, 64, 1.5, "jitter"),
 ])
 def test_hip_matches_oracle(b, n, P, alpha, kind, dev):
     rng = np.random.default_rng(n + P)
     if kind == "lattice":
         x = (rng.integers(0, 6, (b, n, 3)) / 5).astype(np.float32)
+    elif kind == "jitter":
+        # lattice points moved by a few ulps: squared lengths that differ in their last bits while their
+        # rounded square roots tie -- the kernel decides on squared lengths and must fall back to sqrtf
+        x = (rng.integers(0, 8, (b, n, 3)) / 8).astype(np.float32)
+        x = (x + rng.integers(-3, 4, (b, n, 3)).astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
     else:
         x = rng.random((b, n, 3), dtype=np.float32)
     d0, a0, m0 = oracle.expansion_forward(x, P, alpha)
