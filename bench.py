@@ -11,6 +11,10 @@ B=32 clouds of N=16384 points each rank -- BASELINE.json configs[1] + configs[2]
     expansion penalty           fwd + bwd   primitive_size 512, alpha 1.5
     ComputeDepthMaps render     fwd + bwd   8 views x radius_list, 256 x 256
     scalar losses               all-reduce (RCCL) when N > 1
+The four parts are independent given the predicted cloud; by default the renderer runs on a second
+HIP stream next to the distance losses (config.streams = 2; --no-overlap times the one-stream step).
+After the timed region the same steps run once more one stream at a time, untimed for `value`, to
+report per-part times and the kernels' uncontended durations (roofline.isolated).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
   value             point pairs per second, whole job (CD pairs 2*B*N*M + EMD effective pairs
                     sum_it sum_b unassigned*n, counted on the device) / wall time of the steps
@@ -53,6 +57,8 @@ def parse():
                          "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="time the sequential one-stream step instead of the two-stream one")
     ap.add_argument("--no-other-ops", action="store_true",
                     help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
     return ap.parse_args()
@@ -87,6 +93,7 @@ class HotPath:
         self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
         self.ev = {}
         self.last_mean_mst = None
+        self.side = None
 
     def _emd(self, pred, gt):
         """emdFunction with the effective-pair counter attached."""
@@ -108,14 +115,32 @@ class HotPath:
 
         return _Counted.apply(pred, gt)
 
-    def step(self, pred, gt, timers=None):
-        def mark(name):
-            if timers is not None:
-                e = torch.cuda.Event(enable_timing=True)
-                e.record()
-                timers.append((name, e))
+    def _render_all(self, pred):
+        p4 = (pred.detach() - 0.5).requires_grad_(True)
+        acc = None
+        for v in range(N_VIEWS):
+            maps = self.render(p4, view_id=v, radius_list=self.radius_list)
+            s = maps.mean()
+            acc = s if acc is None else acc + s
+        acc.backward()
+        return acc
 
-        mark("start")
+    def step_overlapped(self, pred, gt):
+        """The same step with the renderer on a second HIP stream: the four parts are independent
+        given the predicted cloud, and the renderer's kernels fill the CUs the late (few-bidder) auction
+        iterations leave idle.  Same kernels, same results; per-kernel durations stretch under contention."""
+        main = torch.cuda.current_stream()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            acc = self._render_all(pred)
+        loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt)
+        main.wait_stream(self.side)
+        losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
+        return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
+
+    def _distance_losses(self, pred, gt, mark=lambda name: None):
         p = pred.detach().requires_grad_(True)
         g = gt.detach().requires_grad_(True)
         d1, d2 = self.cd(p, g)
@@ -133,13 +158,19 @@ class HotPath:
         loss_exp.backward()
         self.last_mean_mst = mml.detach()
         mark("expansion")
-        p4 = (pred.detach() - 0.5).requires_grad_(True)
-        acc = None
-        for v in range(N_VIEWS):
-            maps = self.render(p4, view_id=v, radius_list=self.radius_list)
-            s = maps.mean()
-            acc = s if acc is None else acc + s
-        acc.backward()
+        return loss_cd, loss_emd, loss_exp
+
+    def step(self, pred, gt, timers=None):
+        """Sequential step on the current stream, with per-part event marks."""
+        def mark(name):
+            if timers is not None:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                timers.append((name, e))
+
+        mark("start")
+        loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt, mark)
+        acc = self._render_all(pred)
         mark("render")
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
         losses = reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
@@ -286,8 +317,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    overlap = not args.no_overlap
+    run_step = hp.step_overlapped if overlap else hp.step
     for _ in range(args.warmup):
-        hp.step(pred, gt)
+        run_step(pred, gt)
     barrier()
     hp.stats.zero_()
     timers = []
@@ -297,10 +330,37 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses = hp.step(pred, gt, timers)
+        losses = run_step(pred, gt, timers) if not overlap else run_step(pred, gt)
     barrier()
     elapsed = time.perf_counter() - t0
     lib.sn_prof_enable(0)
+    stats_timed = hp.stats.clone()
+
+    def read_kernels():
+        ks = {}
+        for kname in ("chamfer_fwd", "emd_bid", "expansion_fwd", "p2i_max_splat"):
+            ms = ctypes.c_double(0.0)
+            cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
+            ks[kname] = {"launches": int(cnt), "total_ms": ms.value,
+                         "avg_us": (ms.value / cnt * 1e3) if cnt else None}
+        return ks
+
+    kernels = read_kernels() if not args.no_roofline else {}
+    # outside the timed region: the same steps one stream at a time, for the per-part times and for
+    # the kernels' uncontended durations
+    kernels_isolated, isolated_ms = {}, None
+    if overlap and not args.no_roofline:
+        lib.sn_prof_reset()
+        lib.sn_prof_enable(1)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            hp.step(pred, gt, timers)
+        barrier()
+        isolated_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        lib.sn_prof_enable(0)
+        kernels_isolated = read_kernels()
+    hp.stats.copy_(stats_timed)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     pairs_emd = hp.stats[0:1].to(torch.float64)
@@ -322,13 +382,7 @@ def main():
     seg = {k: v / args.steps for k, v in seg.items()}
 
     roofline = None
-    kernels = {}
     if not args.no_roofline:
-        for kname in ("chamfer_fwd", "emd_bid", "expansion_fwd", "p2i_max_splat"):
-            ms = ctypes.c_double(0.0)
-            cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
-            kernels[kname] = {"launches": int(cnt), "total_ms": ms.value,
-                              "avg_us": (ms.value / cnt * 1e3) if cnt else None}
         bid = kernels["emd_bid"]
         if bid["launches"]:
             flops = FLOP_PER_PAIR["emd_bid"] * float(hp.stats[0].item())     # this rank
@@ -349,6 +403,14 @@ def main():
                 "launches": bid["launches"], "avg_launch_us": bid["avg_us"],
                 "pairs_per_launch_avg": float(hp.stats[0].item()) / bid["launches"],
             }
+            iso = kernels_isolated.get("emd_bid")
+            if iso and iso["launches"]:
+                ach = flops / (iso["total_ms"] * 1e-3) / 1e12
+                roofline["isolated"] = {
+                    "achieved": ach, "frac": ach / PEAK_F32_TFLOPS, "avg_launch_us": iso["avg_us"],
+                    "note": ("the same steps run one stream at a time after the timed region; in the "
+                             "timed region the renderer runs on a second stream next to the auction "
+                             "and every kernel's duration includes that contention")}
             cf = kernels["chamfer_fwd"]
             if cf["launches"]:
                 roofline["chamfer_fwd"] = {
@@ -380,12 +442,14 @@ def main():
                              "alpha 1.5) fwd+bwd on [32,16384,3]; ComputeDepthMaps 8 views x radii "
                              f"{radius_list} px -> 256x256 fwd+bwd; scalar-loss all-reduce"),
                 "batch_per_gpu": B, "points": N, "emd_iters": EMD_ITERS, "radius_list": radius_list,
-                "image": IMG, "views": N_VIEWS,
+                "image": IMG, "views": N_VIEWS, "streams": 2 if overlap else 1,
             },
             "pairs_per_step": pairs_total / args.steps / world,
             "maps_per_step": maps_total / args.steps / world,
             "segments_ms_rank0": seg,
+            "sequential_ms_per_step_rank0": isolated_ms,
             "kernels_rank0": kernels,
+            "kernels_isolated_rank0": kernels_isolated,
             "losses": [float(x) for x in losses.tolist()],
             "roofline": roofline,
         }
