@@ -741,7 +741,7 @@ int lin_blocks(long total) {
 // fp32 terms to ~2^-45 of the largest possible term.  The XCD-aware map keeps all pixels of an
 // image, hence all atomics on its points, inside one XCD's L2.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void p2i_absmax_kernel(const float *__restrict__ a, long na,
+__global__ __launch_bounds__(1024) void p2i_absmax_kernel(const float *__restrict__ a, long na,
                                                          const float *__restrict__ b, long nb,
                                                          unsigned *__restrict__ out2) {
   float ma = 0.f, mb = 0.f;
@@ -753,17 +753,18 @@ __global__ __launch_bounds__(256) void p2i_absmax_kernel(const float *__restrict
     ma = __builtin_fmaxf(ma, __shfl_xor(ma, m));
     mb = __builtin_fmaxf(mb, __shfl_xor(mb, m));
   }
-  __shared__ float red[2][4];
+  __shared__ float red[2][16];
   if ((threadIdx.x & 63) == 0) {
     red[0][threadIdx.x >> 6] = ma;
     red[1][threadIdx.x >> 6] = mb;
   }
   __syncthreads();
   if (threadIdx.x == 0) {  // |x| >= 0: the bit patterns order like the values
-    for (int i = 1; i < 4; ++i) {
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) {
       ma = __builtin_fmaxf(ma, red[0][i]);
       mb = __builtin_fmaxf(mb, red[1][i]);
     }
+    // same-address atomics serialise (~25 ns each): 128 large blocks, not 512 small ones
     atomicMax(out2 + 0, __float_as_uint(ma));
     atomicMax(out2 + 1, __float_as_uint(mb));
   }
@@ -1104,7 +1105,7 @@ extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_i
   long long *acc_pts = reinterpret_cast<long long *>(static_cast<char *>(workspace) + 256);
   long long *acc_feat = acc_pts + (size_t)npoints * 2;
   SN_HIP(hipMemsetAsync(workspace, 0, sn_p2i_max_backward_multi_workspace_bytes(npoints, channels), s));
-  p2i_absmax_kernel<<<512, 256, 0, s>>>(out_grad, px * nradii, feat,
+  p2i_absmax_kernel<<<128, 1024, 0, s>>>(out_grad, px * nradii, feat,
                                                            (long)npoints * channels, absmax);
   const long per_image = (long)channels * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);  // tiles
   const long blocks = (per_image + 3) / 4 * 8 * ((batch + 7) / 8);
