@@ -401,6 +401,25 @@ struct GroupAcc {  // per bidder group of a workgroup: the arrival-order merge o
   int lock, arrived;
 };
 
+// min / max over each row of 16 lanes, left in every lane of the row (four DPP steps)
+__device__ __forceinline__ float row16_min(float v) {
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 // level-1 threshold T' of one bidder: base = slack - |x|^2 is fixed, cm grows
 __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_max) {
   const float r = a_max - filter_thr(cm);
@@ -474,7 +493,9 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
     Top2 top = {-1e9f, -1e9f, -1, -1};
 
     if (grp < ngroups) {  // wave-uniform
-      float blo[3], bhi[3];  // wave-uniform bounding box of the wave's bidders
+      // wave-uniform bounding boxes of the wave's four subgroups of 16 bidders (lanes 16 g ..
+      // 16 g + 15 = the bidders MFMA group g filters for)
+      float blo[4][3], bhi[4][3];
       float own_slack2;      // 2 x the filter slack of this lane's own bidder
       {
         const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
@@ -485,15 +506,12 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
           const float v[3] = {x1, y1, z1};
 #pragma unroll
           for (int a = 0; a < 3; ++a) {
-            blo[a] = active ? v[a] : 3.0e38f;
-            bhi[a] = active ? v[a] : -3.0e38f;
-            for (int m = 1; m < 64; m <<= 1) {
-              blo[a] = __builtin_fminf(blo[a], __shfl_xor(blo[a], m));
-              bhi[a] = __builtin_fmaxf(bhi[a], __shfl_xor(bhi[a], m));
+            const float lo = row16_min(active ? v[a] : 3.0e38f), hi = row16_max(active ? v[a] : -3.0e38f);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // wave-uniform: they live in SGPRs
+              blo[g][a] = lane_value(lo, 16 * g);
+              bhi[g][a] = lane_value(hi, 16 * g);
             }
-            // wave-uniform: keep them in SGPRs
-            blo[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(blo[a])));
-            bhi[a] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(bhi[a])));
           }
         }
         // seed the filter with the bidder's previous two favourites under today's prices:
@@ -565,28 +583,37 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
       // superblock whose bounding box is farther than that from the bidders' box cannot produce a
       // single hit -- skipping it changes nothing.  64 superblocks are tested at a time, lane =
       // superblock; the reach shrinks as the thresholds tighten.
-      float r2max;
+      float r2g[4];  // per subgroup
       auto refresh_reach = [&]() {
-        float v = active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f;
-        for (int m = 1; m < 64; m <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m));
-        v = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
-        r2max = v > 0.f ? v * 1.0001f : v;
+        const float v = row16_max(active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float r = lane_value(v, 16 * g);
+          r2g[g] = r > 0.f ? r * 1.0001f : r;
+        }
       };
       refresh_reach();
       const f4 *ms = mstream + (size_t)b * nsb * 64 + lane;
       const float *sbb = sbbox + (size_t)b * nsb * 8;
+      // bit g: superblock sbl can hold a hit for a bidder of subgroup g
       auto worth = [&](int sbl) {
         const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8);
         const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8 + 4);
-        const float gx = __builtin_fmaxf(__builtin_fmaxf(lo4.x - bhi[0], blo[0] - lo4.w), 0.f);
-        const float gy = __builtin_fmaxf(__builtin_fmaxf(lo4.y - bhi[1], blo[1] - hi4.x), 0.f);
-        const float gz = __builtin_fmaxf(__builtin_fmaxf(lo4.z - bhi[2], blo[2] - hi4.y), 0.f);
-        return ((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2max;
+        unsigned m = 0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float gx = __builtin_fmaxf(__builtin_fmaxf(lo4.x - bhi[g][0], blo[g][0] - lo4.w), 0.f);
+          const float gy = __builtin_fmaxf(__builtin_fmaxf(lo4.y - bhi[g][1], blo[g][1] - hi4.x), 0.f);
+          const float gz = __builtin_fmaxf(__builtin_fmaxf(lo4.z - bhi[g][2], blo[g][2] - hi4.y), 0.f);
+          m |= (((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2g[g] ? 1u : 0u) << g;
+        }
+        return m;
       };
       for (int sb0 = 0; sb0 < nsb; sb0 += 64) {
         const int sbl = sb0 + lane;
         const bool mine = sbl < nsb && (sbl & (S - 1)) == seg;
-        unsigned long long todo = __ballot(mine && worth(sbl));
+        unsigned gmask = mine ? worth(sbl) : 0u;  // lane = superblock
+        unsigned long long todo = __ballot(gmask != 0u);
         f4 a_next = {0.f, 0.f, 0.f, 0.f};
         int next_sb = -1;  // superblock whose operand is already in flight
         while (todo) {
@@ -599,8 +626,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
             a_next = ms[(size_t)next_sb * 64];
           }
           bool drained = false;
+          const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, sb - sb0);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
+            if (!((gm >> g) & 1u)) continue;  // wave-uniform: no bidder of this subgroup reaches the superblock
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
             const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
             const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
@@ -635,7 +664,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
             for (int gg = 0; gg < 4; ++gg)
               thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
             refresh_reach();
-            if (todo) todo = __ballot(((todo >> lane) & 1ull) && worth(sbl));
+            if (todo) {
+              gmask = ((todo >> lane) & 1ull) ? worth(sbl) : 0u;
+              todo = __ballot(gmask != 0u);
+            }
           }
         }
       }
