@@ -162,7 +162,7 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
 //    4 such operands; lane l's four values sit in one float4:
 //      mstream[(superblock * 64 + l)].q = component (l >> 4) of target 64 sb + 16 q + (l & 15)
 //    so a wave fetches 64 targets with one coalesced global_load_dwordx4 per lane.
-//  * sbbox: the bounding box of every superblock, for the pruning test.
+//  * sbbox: the bounding box of every block of 16 targets, for the pruning test.
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 struct EmdWs {
@@ -182,7 +182,7 @@ struct EmdWs {
   int *cell_of;  // [B, n] sort scratch
   int *hist;     // [B, 4096] cell offsets of the sorted targets
   float *bbox;   // [B, 6] bounding box of the targets (also bounds |t|^2 for the filter slack)
-  float *sbbox;  // [B, n/64, 8] bounding box of every 64-target superblock of the stream
+  float *sbbox;  // [B, n/16, 8] bounding box of every block of 16 targets of the stream
   int *perm1;    // [B, n] Morton rank -> bidder index
   int *rank1;    // [B, n] bidder index -> Morton rank
   int *flags;    // [B, n] by rank: unassigned after this iteration (next list = flagged ranks in order)
@@ -230,7 +230,27 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
   }
 }
 
-// bounding box of every superblock (64 consecutive targets of the Morton-ordered stream)
+// min / max over each row of 16 lanes, left in every lane of the row (four DPP steps)
+__device__ __forceinline__ float row16_min(float v) {
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
+  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
+  return v;
+}
+__device__ __forceinline__ float lane_value(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+// bounding box of every block of 16 consecutive targets of the Morton-ordered stream (the rows of one
+// MFMA A operand); four of them make a superblock
 __global__ __launch_bounds__(256) void emd_sbbox_kernel(int B, int n, const float *__restrict__ xyz2,
                                                         EmdWs ws) {
   const long sb_all = (long)B * (n >> 6);
@@ -238,16 +258,16 @@ __global__ __launch_bounds__(256) void emd_sbbox_kernel(int B, int n, const floa
   for (long sb = (long)blockIdx.x * 4 + (threadIdx.x >> 6); sb < sb_all; sb += (long)gridDim.x * 4) {
     const long bb = sb / (n >> 6);
     const float *t = xyz2 + (bb * n + ws.tperm[sb * 64 + lane]) * 3;
-    float lo[3] = {t[0], t[1], t[2]}, hi[3] = {t[0], t[1], t[2]};
+    float lo[3], hi[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
-      for (int m = 1; m < 64; m <<= 1) {
-        lo[a] = __builtin_fminf(lo[a], __shfl_xor(lo[a], m));
-        hi[a] = __builtin_fmaxf(hi[a], __shfl_xor(hi[a], m));
-      }
-    if (lane < 8)
-      ws.sbbox[sb * 8 + lane] = lane == 0 ? lo[0] : lane == 1 ? lo[1] : lane == 2 ? lo[2]
-                              : lane == 3 ? hi[0] : lane == 4 ? hi[1] : lane == 5 ? hi[2] : 0.f;
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = row16_min(t[a]);
+      hi[a] = row16_max(t[a]);
+    }
+    const int c = lane & 15;
+    if (c < 8)
+      ws.sbbox[(sb * 4 + (lane >> 4)) * 8 + c] = c == 0 ? lo[0] : c == 1 ? lo[1] : c == 2 ? lo[2]
+                                               : c == 3 ? hi[0] : c == 4 ? hi[1] : c == 5 ? hi[2] : 0.f;
   }
 }
 
@@ -400,25 +420,6 @@ struct GroupAcc {  // per bidder group of a workgroup: the arrival-order merge o
   int bi[64], bi2[64];
   int lock, arrived;
 };
-
-// min / max over each row of 16 lanes, left in every lane of the row (four DPP steps)
-__device__ __forceinline__ float row16_min(float v) {
-  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
-  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
-  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
-  v = __builtin_fminf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
-  return v;
-}
-__device__ __forceinline__ float row16_max(float v) {
-  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true)));
-  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true)));
-  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true)));
-  v = __builtin_fmaxf(v, __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true)));
-  return v;
-}
-__device__ __forceinline__ float lane_value(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
-}
 
 // level-1 threshold T' of one bidder: base = slack - |x|^2 is fixed, cm grows
 __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_max) {
@@ -594,11 +595,11 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
       };
       refresh_reach();
       const f4 *ms = mstream + (size_t)b * nsb * 64 + lane;
-      const float *sbb = sbbox + (size_t)b * nsb * 8;
-      // bit g: superblock sbl can hold a hit for a bidder of subgroup g
-      auto worth = [&](int sbl) {
-        const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8);
-        const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)sbl * 8 + 4);
+      const float *sbb = sbbox + (size_t)b * nsb * 32;
+      // bit g: block `blk` of 16 targets can hold a hit for a bidder of subgroup g
+      auto worth = [&](int blk) {
+        const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)blk * 8);
+        const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)blk * 8 + 4);
         unsigned m = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -609,32 +610,47 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
         }
         return m;
       };
-      for (int sb0 = 0; sb0 < nsb; sb0 += 64) {
-        const int sbl = sb0 + lane;
-        const bool mine = sbl < nsb && (sbl & (S - 1)) == seg;
-        unsigned gmask = mine ? worth(sbl) : 0u;  // lane = superblock
-        unsigned long long todo = __ballot(gmask != 0u);
+      // the nibbles of a quad of lanes side by side: bit 4 q + g of superblock (lane >> 2)
+      auto quad_mask = [&](unsigned m) {
+        const unsigned m0 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x00, 0xf, 0xf, true);  // quad_perm 0,0,0,0
+        const unsigned m1 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x55, 0xf, 0xf, true);  // 1,1,1,1
+        const unsigned m2 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xAA, 0xf, 0xf, true);  // 2,2,2,2
+        const unsigned m3 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xFF, 0xf, 0xf, true);  // 3,3,3,3
+        return m0 | (m1 << 4) | (m2 << 8) | (m3 << 12);
+      };
+      // Lane 4 i + q tests block q of the wave's i-th own superblock (superblock i S + seg): 16 own
+      // superblocks per pass.
+      const int owned4 = (nsb / S) * 4;
+      for (int t0 = 0; t0 < owned4; t0 += 64) {
+        const int task = t0 + lane;
+        const int sbl = (task >> 2) * S + seg;
+        const bool mine = task < owned4;
+        unsigned gmask = quad_mask(mine ? worth(sbl * 4 + (task & 3)) : 0u);
+        unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
         f4 a_next = {0.f, 0.f, 0.f, 0.f};
         int next_sb = -1;  // superblock whose operand is already in flight
         while (todo) {
-          const int sb = sb0 + __builtin_ctzll(todo);
+          const int tl = __builtin_ctzll(todo);
+          const int sb = ((t0 + tl) >> 2) * S + seg;
           todo &= todo - 1;
           const int kb = sb * 64;
           const f4 a = sb == next_sb ? a_next : ms[(size_t)sb * 64];
           if (todo) {
-            next_sb = sb0 + __builtin_ctzll(todo);
+            next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
             a_next = ms[(size_t)next_sb * 64];
           }
           bool drained = false;
-          const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, sb - sb0);
+          const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, tl);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            if (!((gm >> g) & 1u)) continue;  // wave-uniform: no bidder of this subgroup reaches the superblock
+            if (!(gm & (0x1111u << g))) continue;  // wave-uniform: nothing for this subgroup here
             const f4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
-            const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
-            const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
-            const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+            const f4 far = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+            // only the (block, subgroup) pairs whose boxes are within reach go through the matrix cores
+            const f4 d0 = (gm >> g) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0) : far;
+            const f4 d1 = (gm >> (4 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0) : far;
+            const f4 d2 = (gm >> (8 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0) : far;
+            const f4 d3 = (gm >> (12 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0) : far;
             if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
               // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
               unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
@@ -659,14 +675,15 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
               }
             }
           }
-          if (drained) {  // tighter thresholds: less reach, fewer superblocks left to visit
+          if (drained) {  // tighter thresholds: less reach, fewer blocks left to visit
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg)
               thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
             refresh_reach();
             if (todo) {
-              gmask = ((todo >> lane) & 1ull) ? worth(sbl) : 0u;
-              todo = __ballot(gmask != 0u);
+              const bool left = (todo >> (lane & ~3)) & 1ull;
+              gmask = quad_mask(left ? worth(sbl * 4 + (task & 3)) : 0u);
+              todo = __ballot(gmask != 0u && (lane & 3) == 0);
             }
           }
         }
@@ -869,7 +886,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.cell_of = reinterpret_cast<int *>(p); p += arr;
   ws.hist = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
   ws.bbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
-  ws.sbbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * (n / 64) * 32, 256);
+  ws.sbbox = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * (n / 16) * 32, 256);
   ws.perm1 = reinterpret_cast<int *>(p); p += arr;
   ws.rank1 = reinterpret_cast<int *>(p); p += arr;
   ws.flags = reinterpret_cast<int *>(p); p += arr;
@@ -884,7 +901,7 @@ extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
   return 15 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
          2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
-         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 64) * 32, 256);
+         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256);
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
