@@ -42,6 +42,14 @@ namespace {
 constexpr int kThreads = 256;     // element-wise kernels
 constexpr int kBlocksPerCloud = SN_EMD_G;  // bid kernel: 32 workgroups x 16 waves = 512 waves per cloud (swept 8..64)
 
+// Optional per-wave phase stamps of the bid kernel (make diag; tools/emd_timeline.py): the 100 MHz
+// wall clock at the phase boundaries and a few counters, 14 int64 per wave after the 8 stats words.
+#ifdef SN_EMD_DIAG
+#define DIAG(...) __VA_ARGS__
+#else
+#define DIAG(...)
+#endif
+
 struct Top2 {
   float best, better;
   int best_i, better_i;  // best_i: canonical among exact ties (see tie_key); better_i: a hint
@@ -490,6 +498,9 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
     const int grp = q0 + gslot;
     const int u = grp * 64 + lane;
     const bool active = grp < ngroups && u < U;
+    DIAG(const long long dg_t0 = __builtin_amdgcn_s_memrealtime(); long long dg_t1 = dg_t0, dg_t2 = dg_t0;
+         long long dg_hit = 0, dg_batch = 0, dg_worth = 0;
+         int dg_vis = 0, dg_nb = 0, dg_hb = 0, dg_mf = 0, dg_q = 0, dg_p2 = 0;)
     const int j = lst[active ? u : 0];
     Top2 top = {-1e9f, -1e9f, -1, -1};
 
@@ -548,9 +559,11 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
         bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
       }
       int qcount = 0;  // wave-uniform
+      DIAG(dg_t1 = __builtin_amdgcn_s_memrealtime();)
 
       // 64 (or the last `count`) queued pairs, one per lane
       auto batch = [&](int first, int count) {
+        DIAG(const long long dg_b0 = __builtin_amdgcn_s_memrealtime(); ++dg_nb;)
         const bool on = lane < count;
         const unsigned e = T.queue[first + (on ? lane : 0)];
         const int c = (int)(e >> 20);
@@ -559,6 +572,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
         const int k = __float_as_int(pq.y);
         const float sq = sq_dist(t.x, t.y, t.z, T.x[c], T.y[c], T.z[c]);
         bool pend = on && filter_pass(sq, t.w, filter_thr(T.cm[c]));  // level 2
+        DIAG(dg_q += count; dg_p2 += __popcll(__ballot(pend));)
         float d = 0.f;
         if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pq.x);
         volatile int *own = T.owner;
@@ -577,6 +591,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
           }
         }
         asm volatile("" ::: "memory");
+        DIAG(dg_batch += __builtin_amdgcn_s_memrealtime() - dg_b0;)
       };
 
       // Superblock pruning.  A pair passes the coarse filter only if |t - x_j|^2 (up to the slack)
@@ -625,8 +640,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
         const int task = t0 + lane;
         const int sbl = (task >> 2) * S + seg;
         const bool mine = task < owned4;
+        DIAG(const long long dg_w0 = __builtin_amdgcn_s_memrealtime();)
         unsigned gmask = quad_mask(mine ? worth(sbl * 4 + (task & 3)) : 0u);
         unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
+        DIAG(dg_worth += __builtin_amdgcn_s_memrealtime() - dg_w0;)
         f4 a_next = {0.f, 0.f, 0.f, 0.f};
         int next_sb = -1;  // superblock whose operand is already in flight
         while (todo) {
@@ -641,6 +658,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
           }
           bool drained = false;
           const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, tl);
+          DIAG(++dg_vis; dg_mf += __builtin_popcount(gm);)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             if (!(gm & (0x1111u << g))) continue;  // wave-uniform: nothing for this subgroup here
@@ -652,6 +670,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
             const f4 d2 = (gm >> (8 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0) : far;
             const f4 d3 = (gm >> (12 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0) : far;
             if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
+              DIAG(const long long dg_h0 = __builtin_amdgcn_s_memrealtime(); ++dg_hb;)
               // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
               unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
                             hits4(d3, thr[g], 12);
@@ -673,6 +692,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
                   drained = true;
                 }
               }
+              DIAG(dg_hit += __builtin_amdgcn_s_memrealtime() - dg_h0;)
             }
           }
           if (drained) {  // tighter thresholds: less reach, fewer blocks left to visit
@@ -690,6 +710,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
       }
       if (qcount > 0) batch(0, qcount);
       top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
+      DIAG(dg_t2 = __builtin_amdgcn_s_memrealtime();)
     }
     // Merge the S partial results of a bidder group in ARRIVAL order, without a barrier: a wave
     // that is done takes the group's lock, folds its partial into the group accumulator (the
@@ -719,6 +740,13 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
       }
     }
     if (emit && active) emit_bid(A, o, j, top, eps);
+    DIAG(if (stats && lane == 0 && q0 == bx * gpb && grp < ngroups) {
+      const long long dg_t3 = __builtin_amdgcn_s_memrealtime();
+      long long *r = stats + 8 + ((size_t)(blockIdx.x % 1024) * 16 + wave) * 14;
+      r[0] = dg_t3; r[1] = dg_t1 - dg_t0; r[2] = dg_t2 - dg_t1; r[3] = dg_t3 - dg_t2; r[4] = dg_vis; r[5] = dg_nb;
+      r[6] = dg_hb; r[7] = dg_hit; r[8] = dg_batch; r[9] = dg_worth; r[10] = dg_mf; r[11] = dg_t0;
+      r[12] = dg_q; r[13] = dg_p2;
+    })
     // the accumulators and tables are reused by the block's next work item
     if (q0 + G * gpb < ngroups) __syncthreads();
   }
