@@ -1,6 +1,8 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])  # A/B a saved build
 from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
 from sparenet_amd import _lib
 dev = torch.device("cuda:0")
