@@ -24,6 +24,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
 """
 import argparse
 import ctypes
+import glob
 import json
 import os
 import sys
@@ -388,9 +389,9 @@ def main():
             flops = FLOP_PER_PAIR["emd_bid"] * float(hp.stats[0].item())     # this rank
             achieved = flops / (bid["total_ms"] * 1e-3) / 1e12
             traffic = None   # PMC passes cannot run inside the bench: committed measurement
-            tfile = os.path.join(ROOT, "profiles", "r01_g_emd_bid_traffic.json")
-            if os.path.isfile(tfile):
-                traffic = json.load(open(tfile)).get("bytes_per_launch_corrected")
+            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_emd_bid_traffic.json")))
+            if tfiles:   # the newest committed PMC measurement (tools/traffic_emd.sh)
+                traffic = json.load(open(tfiles[-1])).get("bytes_per_launch_corrected")
             roofline = {
                 "kernel": "emd_bid_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
