@@ -282,9 +282,10 @@ def other_ops(dev, pred, mean_mst):
         cubic(q, feats).sum().backward()
     out["cubic_sampling_2048x32c_fwd_bwd"] = ms(cubic_fb)
     # EdgeConv graph of the generator (models/sparenet_generator.py:192-209): 3000 input points, k = 8
-    from sparenet_amd.cuda.knn import get_graph_feature, knn
+    from sparenet_amd.cuda.knn import get_graph_feature, knn, knn_unfused
     xf = torch.rand(B, 256, 3000, generator=g).to(dev).requires_grad_(True)
-    out["knn_k8_c256_n3000"] = ms(lambda: knn(xf.detach(), 8))
+    out["knn_k8_c256_n3000"] = ms(lambda: knn(xf.detach(), 8))            # fused fp32 MFMA kernel
+    out["knn_k8_c256_n3000_gemm_plus_rank"] = ms(lambda: knn_unfused(xf.detach(), 8))
     nbr = knn(xf.detach(), 8)
 
     def graph_fb():

@@ -212,6 +212,13 @@ int sn_p2i_sum_backward(const float *out_grad, const float *points,
  * itself comes first); k in {1, 2, 4, 8, 16, 20, 32}. */
 int sn_knn_topk(const float *inner, const float *xx, int b, int n, int k,
                 long long *idx, void *stream);
+/* The same search as ONE kernel on the fp32 matrix cores, from x[b,c,n] directly: the score tiles
+ * 2 x_i.x_j - |x_j|^2 live in the MFMA accumulators and every lane keeps the k best of its queries
+ * in registers, so the [b,n,n] matrix is never written (knn_mfma.hip).  idx[b,n,k] as above, the
+ * point itself first; 1 <= k <= 20.  workspace: sn_knn_workspace_bytes(b, n) (the squared norms). */
+size_t sn_knn_workspace_bytes(int b, int n);
+int sn_knn(const float *x, int b, int c, int n, int k, long long *idx,
+           void *workspace, size_t workspace_bytes, void *stream);
 /* x[b,c,n], idx[b,n,k] -> out[b,2c,n,k]: out[:, ch] = x[idx] - x, out[:, c + ch] = x
  * (cat((feature - x, x), dim=3).permute(0, 3, 1, 2), :899-905); backward: grad_x[b,c,n]. */
 int sn_graph_feature_forward(const float *x, const long long *idx, int b, int c,

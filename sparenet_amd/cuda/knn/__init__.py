@@ -3,9 +3,11 @@
 sn_graph_feature_forward / backward (include/sparenet_hip.h).
 
 The reference's GPU branch calls the un-vendored KNN_CUDA wheel; its CPU branch ranks
--|x_i|^2 + 2 x_i.x_j - |x_j|^2 with topk.  Here the inner products are one batched GEMM
-(torch.bmm = rocBLAS) and the ranking is a HIP kernel; neighbours come out ascending by distance, the
-point itself first, equal scores by lower index.
+-|x_i|^2 + 2 x_i.x_j - |x_j|^2 with topk.  For k <= 8 (SpareNet's EdgeConv) the whole search is ONE kernel on the fp32 matrix
+cores (sn_knn, knn_mfma.hip: score tiles in the MFMA accumulators, the k best of every query in registers,
+no [B,N,N] matrix in HBM); larger k takes the inner products from one batched GEMM (torch.bmm = rocBLAS)
+and ranks them with sn_knn_topk.  Neighbours come out ascending by distance, the point itself first,
+equal scores by lower index.
 """
 import ctypes
 
@@ -13,11 +15,32 @@ import torch
 
 from sparenet_amd import _lib
 
+FUSED_MAX_K = 8    # sn_knn accepts k <= 20; above 8 the GEMM + ranking pair is faster (measured)
+
 
 def knn(x, k: int):
     """x [B, C, N] float32 on the GPU -> idx [B, N, k] int64 (indices of the k nearest points)."""
     if x.dim() != 3:
         raise ValueError("knn expects x [batch, feature_dim, num_points]")
+    return knn_fused(x, k) if k <= FUSED_MAX_K else knn_unfused(x, k)
+
+
+def knn_fused(x, k: int):
+    """The one-kernel search on the fp32 matrix cores (sn_knn); k <= 20."""
+    x = x.contiguous().float()
+    b, c, n = x.shape
+    idx = torch.empty(b, n, k, dtype=torch.int64, device=x.device)
+    with torch.cuda.device_of(x):
+        nbytes = _lib.lib().sn_knn_workspace_bytes(b, n)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        code = _lib.lib().sn_knn(_lib.fptr(x, "x"), b, c, n, int(k), ctypes.c_void_p(idx.data_ptr()),
+                                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(x))
+    _lib.check(code, "sn_knn")
+    return idx
+
+
+def knn_unfused(x, k: int):
+    """The two-step path (library GEMM + sn_knn_topk); any k <= 32."""
     x = x.contiguous().float()
     b, _, n = x.shape
     inner = torch.bmm(x.transpose(2, 1), x).contiguous()        # [B, N, N]

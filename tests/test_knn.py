@@ -60,13 +60,16 @@ def test_hip_knn_and_graph_feature(golden_dir, dev):
 def test_hip_knn_sparenet_sizes_and_autograd(dev):
     """The generator's EdgeConv sizes (3000 points, C = 3 and 256, k = 8) against the oracle, and the
     gradient of the edge features against torch's own gather formulation."""
-    from sparenet_amd.cuda.knn import get_graph_feature, knn
+    from sparenet_amd.cuda.knn import get_graph_feature, knn, knn_fused, knn_unfused
 
     g = torch.Generator().manual_seed(5)
     for c in (3, 256):
         x = torch.rand(2, c, 3000, generator=g)
-        idx = knn(x.to(dev), 8)
-        assert _rows_match(idx.cpu().numpy(), oracle.knn(x.numpy(), 8), x.numpy(), 8) == 0
+        ref = oracle.knn(x.numpy(), 8)
+        for fn in (knn_fused, knn_unfused):   # the fused MFMA kernel and the GEMM + ranking pair
+            idx = fn(x.to(dev), 8)
+            assert _rows_match(idx.cpu().numpy(), ref, x.numpy(), 8) == 0, fn.__name__
+            assert (idx[:, :, 0].cpu() == torch.arange(3000)[None]).all()
     x = torch.rand(2, 5, 300, generator=g).to(dev).requires_grad_(True)
     w = torch.rand(2, 10, 300, 4, generator=g).to(dev)
     idx = knn(x.detach(), 4)
@@ -76,3 +79,34 @@ def test_hip_knn_sparenet_sizes_and_autograd(dev):
     ref = torch.cat([nb - x2.unsqueeze(3), x2.unsqueeze(3).expand(-1, -1, -1, 4)], dim=1)
     (ref * w).sum().backward()
     np.testing.assert_allclose(x.grad.cpu().numpy(), x2.grad.cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,c,n,k", [(1, 3, 130, 4), (2, 17, 257, 8), (3, 64, 1000, 20), (2, 5, 64, 16),
+                                     (1, 512, 515, 8), (2, 33, 129, 1), (1, 7, 24, 20)])
+def test_hip_fused_knn_shapes(b, c, n, k, dev):
+    """Ragged sizes of the fused kernel: n not a multiple of the 128-point tile or of 4 (scalar loads),
+    channel counts that do not fill a 16-channel stage, k at both list sizes, k close to n."""
+    from sparenet_amd.cuda.knn import knn_fused
+
+    g = torch.Generator().manual_seed(b * 1000 + c * 10 + k)
+    x = torch.randn(b, c, n, generator=g)
+    idx = knn_fused(x.to(dev), k).cpu().numpy()
+    assert idx.shape == (b, n, k) and idx.min() >= 0 and idx.max() < n
+    assert (idx[:, :, 0] == np.arange(n)[None]).all()
+    for row in idx.reshape(-1, k):
+        assert len(set(row.tolist())) == k
+    assert _rows_match(idx, oracle.knn(x.numpy(), k), x.numpy(), k) == 0
+
+
+@pytest.mark.gpu
+def test_hip_fused_knn_ties(dev):
+    """Duplicate points: equal scores resolve to the lower index, the point itself stays first."""
+    from sparenet_amd.cuda.knn import knn_fused as knn
+
+    base = torch.tensor([[0.0, 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [5.0, 5.0, 5.0]]).t()   # [3, 4]
+    x = base.repeat(1, 40).unsqueeze(0).contiguous()                       # [1, 3, 160]: every point 40 times
+    idx = knn(x.to(dev), 8).cpu().numpy()[0]
+    for i in range(160):
+        same = [j for j in range(160) if j % 4 == i % 4 and j != i]
+        assert idx[i, 0] == i and list(idx[i, 1:]) == same[:7], (i, idx[i])
