@@ -1,4 +1,4 @@
-// cloud_sort.hpp -- counting sort of a point cloud into 16^3 Morton cells (gfx950 only).
+// cloud_sort.hpp -- counting sort of a point cloud into the 16^3 cells of a Hilbert curve (gfx950 only).
 // Shared by MDS (cluster-sorted slots) and EMD (spatially ordered target stream, seeds).
 // Two launches per batch of clouds:
 //   cloud_sort_count_kernel    one workgroup per cloud: bounding box, cell of every point,
@@ -10,14 +10,51 @@
 
 namespace {
 
-constexpr int kSortCells = 4096;  // 16^3 Morton cells
+constexpr int kSortCells = 4096;  // 16^3 cells
 
+// Cell code along a 3-D Hilbert curve over the 16^3 grid (Skilling's axes-to-transpose form, then the
+// bits interleaved): consecutive codes are face-adjacent cells, so a run of sorted points -- an MDS slot,
+// an EMD / Chamfer block of 16 or 64 -- is one compact blob.  Z order jumps at every octant boundary,
+// which stretched the bounding boxes the pruning tests use.  (The name is kept: every caller only needs
+// "the sort key of a cell".)
 __device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigned z) {
+#ifdef SN_SORT_Z_ORDER
   unsigned r = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
     r |= (((x >> i) & 1u) << (3 * i)) | (((y >> i) & 1u) << (3 * i + 1)) | (((z >> i) & 1u) << (3 * i + 2));
   return r;
+#else
+  unsigned X[3] = {x, y, z};
+#pragma unroll
+  for (unsigned q = 8u; q > 1u; q >>= 1) {
+    const unsigned p = q - 1u;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      if (X[i] & q) {
+        X[0] ^= p;
+      } else {
+        const unsigned t = (X[0] ^ X[i]) & p;
+        X[0] ^= t;
+        X[i] ^= t;
+      }
+    }
+  }
+  X[1] ^= X[0];
+  X[2] ^= X[1];
+  unsigned t = 0;
+#pragma unroll
+  for (unsigned q = 8u; q > 1u; q >>= 1)
+    if (X[2] & q) t ^= q - 1u;
+  X[0] ^= t;
+  X[1] ^= t;
+  X[2] ^= t;
+  unsigned r = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r |= (((X[0] >> i) & 1u) << (3 * i + 2)) | (((X[1] >> i) & 1u) << (3 * i + 1)) | (((X[2] >> i) & 1u) << (3 * i));
+  return r;
+#endif
 }
 
 // per cloud: bounding box -> cell histogram (one workgroup per cloud)
