@@ -148,8 +148,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(int B, NnSide S1, NnSide
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float ext = box[3 + a] - box[a];
-      const float f = ext > 0.f ? (v[a] - box[a]) * (15.999f / ext) : 0.f;
-      cq[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
+      cq[a] = sort_coord(v[a], box[a], sort_scale(ext));
     }
     const int c = (int)morton3_4bit(cq[0], cq[1], cq[2]);
     const int start = c > 0 ? T.hist[b * kSortCells + c - 1] : 0;  // END of the previous cell
@@ -360,7 +359,8 @@ extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, i
   for (NnSide *side : {&s1, &s2}) {
     const long total = (long)b * side->n;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    cloud_sort_count_kernel<<<b, 1024, 0, s>>>(side->n, side->xyz, side->bbox, side->hist, cell_of);
+    SN_REQUIRE(cloud_sort_count(b, side->n, side->xyz, side->bbox, side->hist, cell_of, s) == 0,
+               "sn_chamfer_forward_sorted: cannot size the sort kernel's LDS");
     cloud_sort_scatter_kernel<<<blocks, 256, 0, s>>>(side->n, cell_of, side->hist, side->perm, total);
     const long sbs = (long)b * side->nsb;
     nn_prepare_kernel<<<(int)((sbs + 3) / 4 < 4096 ? (sbs + 3) / 4 : 4096), 256, 0, s>>>(b, *side);

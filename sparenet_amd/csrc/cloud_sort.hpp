@@ -8,11 +8,27 @@
 #pragma once
 #include "common.hpp"
 
+// 16^3 cells.  32^3 (SN_SORT_BITS=5, 128 KB of counters) was measured: the blocks get no tighter for the
+// pruning tests at 16384 points and the sort itself costs more (Chamfer 0.58 -> 0.64 ms).
+#ifndef SN_SORT_BITS
+#define SN_SORT_BITS 4
+#endif
+
 namespace {
 
-constexpr int kSortCells = 4096;  // 16^3 cells
+constexpr int kSortBits = SN_SORT_BITS;          // grid side 2^bits per axis
+constexpr int kSortSide = 1 << kSortBits;
+constexpr int kSortCells = kSortSide * kSortSide * kSortSide;
 
-// Cell code along a 3-D Hilbert curve over the 16^3 grid (Skilling's axes-to-transpose form, then the
+// grid coordinate of v inside [lo, lo + ext]: the ONE expression every kernel uses, so a point lands in the
+// same cell wherever its cell is recomputed
+__device__ __forceinline__ float sort_scale(float ext) { return ext > 0.f ? ((float)kSortSide - 0.001f) / ext : 0.f; }
+__device__ __forceinline__ unsigned sort_coord(float v, float lo, float scale) {
+  const float f = (v - lo) * scale;
+  return (unsigned)(f < 0.f ? 0.f : (f > (float)(kSortSide - 1) ? (float)(kSortSide - 1) : f));
+}
+
+// Cell code along a 3-D Hilbert curve over the 2^bits-per-axis grid (Skilling's axes-to-transpose form, then the
 // bits interleaved): consecutive codes are face-adjacent cells, so a run of sorted points -- an MDS slot,
 // an EMD / Chamfer block of 16 or 64 -- is one compact blob.  Z order jumps at every octant boundary,
 // which stretched the bounding boxes the pruning tests use.  (The name is kept: every caller only needs
@@ -21,13 +37,13 @@ __device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigne
 #ifdef SN_SORT_Z_ORDER
   unsigned r = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kSortBits; ++i)
     r |= (((x >> i) & 1u) << (3 * i)) | (((y >> i) & 1u) << (3 * i + 1)) | (((z >> i) & 1u) << (3 * i + 2));
   return r;
 #else
   unsigned X[3] = {x, y, z};
 #pragma unroll
-  for (unsigned q = 8u; q > 1u; q >>= 1) {
+  for (unsigned q = 1u << (kSortBits - 1); q > 1u; q >>= 1) {
     const unsigned p = q - 1u;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -44,14 +60,14 @@ __device__ __forceinline__ unsigned morton3_4bit(unsigned x, unsigned y, unsigne
   X[2] ^= X[1];
   unsigned t = 0;
 #pragma unroll
-  for (unsigned q = 8u; q > 1u; q >>= 1)
+  for (unsigned q = 1u << (kSortBits - 1); q > 1u; q >>= 1)
     if (X[2] & q) t ^= q - 1u;
   X[0] ^= t;
   X[1] ^= t;
   X[2] ^= t;
   unsigned r = 0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < kSortBits; ++i)
     r |= (((X[0] >> i) & 1u) << (3 * i + 2)) | (((X[1] >> i) & 1u) << (3 * i + 1)) | (((X[2] >> i) & 1u) << (3 * i));
   return r;
 #endif
@@ -63,7 +79,7 @@ __global__ __launch_bounds__(1024) void cloud_sort_count_kernel(int n, const flo
                                                               int *__restrict__ hist,
                                                               int *__restrict__ cell_of) {
   __shared__ float red[6][16];
-  __shared__ int lh[kSortCells];
+  extern __shared__ int lh[];  // kSortCells counters (128 KB at 32^3: see cloud_sort_count)
   const int b = blockIdx.x, tid = threadIdx.x;
   const float *p = xyz + (size_t)b * n * 3;
   float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(1024) void cloud_sort_count_kernel(int n, const flo
       h = __builtin_fmaxf(h, red[3 + a][w]);
     }
     blo[a] = l;
-    scale[a] = h > l ? 15.999f / (h - l) : 0.f;
+    scale[a] = sort_scale(h - l);
     if (tid == 0) {
       bbox[b * 6 + a] = l;
       bbox[b * 6 + 3 + a] = h;
@@ -106,19 +122,18 @@ __global__ __launch_bounds__(1024) void cloud_sort_count_kernel(int n, const flo
   for (int k = tid; k < n; k += 1024) {
     unsigned q[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float f = (p[k * 3 + a] - blo[a]) * scale[a];
-      q[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
-    }
+    for (int a = 0; a < 3; ++a) q[a] = sort_coord(p[k * 3 + a], blo[a], scale[a]);
     const int c = (int)morton3_4bit(q[0], q[1], q[2]);
     cell_of[(size_t)b * n + k] = c;
     atomicAdd(&lh[c], 1);
   }
   __syncthreads();
-  // exclusive scan of the 4096 cell counts (4 per lane) -> start offsets
-  const int c0 = tid * 4;
-  const int v0 = lh[c0], v1 = lh[c0 + 1], v2 = lh[c0 + 2], v3 = lh[c0 + 3];
-  int sum = v0 + v1 + v2 + v3, incl = sum;
+  // exclusive scan of the cell counts (kSortCells / 1024 consecutive cells per thread) -> start offsets
+  constexpr int kPer = kSortCells / 1024;
+  const int c0 = tid * kPer;
+  int sum = 0;
+  for (int i = 0; i < kPer; ++i) sum += lh[c0 + i];
+  int incl = sum;
   for (int m = 1; m < 64; m <<= 1) {
     const int o = __shfl_up(incl, m);
     if ((tid & 63) >= m) incl += o;
@@ -130,10 +145,23 @@ __global__ __launch_bounds__(1024) void cloud_sort_count_kernel(int n, const flo
   for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
   int ex = base + incl - sum;
   int *h = hist + (size_t)b * kSortCells;
-  h[c0] = ex;
-  h[c0 + 1] = ex + v0;
-  h[c0 + 2] = ex + v0 + v1;
-  h[c0 + 3] = ex + v0 + v1 + v2;
+  for (int i = 0; i < kPer; ++i) {
+    h[c0 + i] = ex;
+    ex += lh[c0 + i];
+  }
+}
+
+// launch of the count kernel: its counters are dynamic LDS (above the 64 KB default at 32^3 cells)
+inline int cloud_sort_count(int b, int n, const float *xyz, float *bbox, int *hist, int *cell_of, hipStream_t s) {
+  static bool attr_set = false;  // per translation unit (the kernel is in an anonymous namespace)
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(cloud_sort_count_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCells * 4) != hipSuccess)
+      return 1;
+    attr_set = true;
+  }
+  cloud_sort_count_kernel<<<b, 1024, kSortCells * 4, s>>>(n, xyz, bbox, hist, cell_of);
+  return 0;
 }
 
 // scatter: perm[sorted position] = original index (order inside a cell is irrelevant)

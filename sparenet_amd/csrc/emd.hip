@@ -301,8 +301,7 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float ext = box[3 + a] - box[a];
-      const float f = ext > 0.f ? (v[a] - box[a]) * (15.999f / ext) : 0.f;
-      q[a] = (unsigned)(f < 0.f ? 0.f : (f > 15.f ? 15.f : f));
+      q[a] = sort_coord(v[a], box[a], sort_scale(ext));
     }
     const int c = (int)morton3_4bit(q[0], q[1], q[2]);
     const int start = c > 0 ? ws.hist[bb * kSortCells + c - 1] : 0;  // END of the previous cell
@@ -947,9 +946,11 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
-  cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz2, ws.bbox, ws.hist, ws.cell_of);
+  SN_REQUIRE(cloud_sort_count(b, n, xyz2, ws.bbox, ws.hist, ws.cell_of, s) == 0,
+             "sn_emd_forward: cannot size the sort kernel's LDS");
   cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist, ws.tperm, total);
-  cloud_sort_count_kernel<<<b, 1024, 0, s>>>(n, xyz1, ws.bbox1, ws.hist1, ws.cell_of);
+  SN_REQUIRE(cloud_sort_count(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, s) == 0,
+             "sn_emd_forward: cannot size the sort kernel's LDS");
   cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist1, ws.perm1, total);
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
