@@ -343,7 +343,10 @@ struct GatherHit {
   unsigned low;     // 0xFFFFFFFE - point id
 };
 
-template <int NR>
+// C1 = single-channel features (ComputeDepthMaps): the feature travels in the sorted record.  As a run-time
+// test the per-channel load sat in a branch next to the record prefetch and hipcc covered both with one
+// s_waitcnt vmcnt(0) -- every batch of 64 candidates waited for the NEXT batch's records to arrive.
+template <int NR, bool C1>
 __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
     const float *__restrict__ feat, const float *__restrict__ background,
     const float4 *__restrict__ srec, const int *__restrict__ offs,
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
         const int pid = __float_as_int(rec.w);
         cpy = rec.x;
         cpx = rec.y;
-        cf = channels == 1 ? rec.z : feat[(size_t)pid * channels + c];
+        cf = C1 ? rec.z : feat[(size_t)pid * channels + c];
         clow = 0xFFFFFFFEu - (unsigned)pid;
       }
       // Cull, 64 candidates at a time (lane = candidate): nearest pixel of the tile out of
@@ -938,8 +941,14 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
                                                                cells_y);
   const int blocks = (int)((tiles + 3) / 4);
 #define SN_GATHER(NR)                                                                         \
-  p2i_gather_max_kernel<NR><<<blocks, 256, 0, s>>>(feat, background, srec, offs, channels,      \
-      batch, h, w, cells_x, cells_y, ra, out, out_ids)
+  do {                                                                                        \
+    if (channels == 1)                                                                        \
+      p2i_gather_max_kernel<NR, true><<<blocks, 256, 0, s>>>(feat, background, srec, offs,      \
+          channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);                         \
+    else                                                                                      \
+      p2i_gather_max_kernel<NR, false><<<blocks, 256, 0, s>>>(feat, background, srec, offs,     \
+          channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);                         \
+  } while (0)
   if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
   switch (nradii) {
     case 1: SN_GATHER(1); break;
