@@ -153,13 +153,10 @@ __global__ __launch_bounds__(1024) void cloud_sort_count_kernel(int n, const flo
 
 // launch of the count kernel: its counters are dynamic LDS (above the 64 KB default at 32^3 cells)
 inline int cloud_sort_count(int b, int n, const float *xyz, float *bbox, int *hist, int *cell_of, hipStream_t s) {
-  static bool attr_set = false;  // per translation unit (the kernel is in an anonymous namespace)
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(cloud_sort_count_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortCells * 4) != hipSuccess)
-      return 1;
-    attr_set = true;
-  }
+  if (kSortCells * 4 > 48 * 1024 &&  // per call: the attribute belongs to the current device
+      hipFuncSetAttribute(reinterpret_cast<const void *>(cloud_sort_count_kernel),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, kSortCells * 4) != hipSuccess)
+    return 1;
   cloud_sort_count_kernel<<<b, 1024, kSortCells * 4, s>>>(n, xyz, bbox, hist, cell_of);
   return 0;
 }

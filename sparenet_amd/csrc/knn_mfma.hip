@@ -257,12 +257,9 @@ size_t knn_lds_bytes() {
 template <int K>
 int launch_knn(const float *x, const float *xx, int b, int c, int n, int k, long long *idx, hipStream_t s) {
   const size_t lds = knn_lds_bytes<K>();
-  static bool attr_set = false;  // per template instance, per process
-  if (!attr_set && lds > 48 * 1024) {
+  if (lds > 48 * 1024)  // per call: the attribute belongs to the current device
     SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_mfma_kernel<K>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
   const dim3 grid((n + kTile - 1) / kTile, b);
   knn_mfma_kernel<K><<<grid, 256, lds, s>>>(x, xx, c, n, k, idx);
   return sn::launch_status("sn_knn");

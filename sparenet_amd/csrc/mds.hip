@@ -607,12 +607,10 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     const size_t lds = (size_t)ppt * 1024 * 8;
 #define SN_MDSC(P)                                                                               \
   {                                                                                              \
-    static bool once = [] {                                                                      \
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_clustered_kernel<P>),       \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) == \
-             hipSuccess;                                                                         \
-    }();                                                                                         \
-    (void)once;                                                                                  \
+    /* every call: the attribute belongs to the CURRENT device (several devices per process under    \
+       DataParallel), it is not a per-process fact */                                            \
+    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_clustered_kernel<P>),         \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));  \
     mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, bbox, mean_mst_length, idx);          \
   }
     // exact slot counts near the register limit (19 at SpareNet's n = 19384): every unused
@@ -640,20 +638,12 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
   else if (ppt <= 16) SN_MDS(16);
   else if (ppt <= 20 && (size_t)n * 8 + 1024 <= 160 * 1024) {
     // y,z of 20480 points = 160 KiB minus the hand-off slots: opt in to the large LDS carve
-    static bool once = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_kernel<20, 2, 1024>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) ==
-             hipSuccess;
-    }();
-    (void)once;
+    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_kernel<20, 2, 1024>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
     SN_MDS_Z(20, 2);
   } else if (ppt <= 24) {
-    static bool once = [] {
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_kernel<24, 1, 1024>),
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) ==
-             hipSuccess;
-    }();
-    (void)once;
+    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_kernel<24, 1, 1024>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     SN_MDS_Z(24, 1);
   }
   else {
