@@ -284,8 +284,13 @@ def other_ops(dev, pred, mean_mst):
     # EdgeConv graph of the generator (models/sparenet_generator.py:192-209): 3000 input points, k = 8
     from sparenet_amd.cuda.knn import get_graph_feature, knn, knn_unfused
     xf = torch.rand(B, 256, 3000, generator=g).to(dev).requires_grad_(True)
-    out["knn_k8_c256_n3000"] = ms(lambda: knn(xf.detach(), 8))            # fused fp32 MFMA kernel
+    from sparenet_amd.cuda.knn import knn_fused
+    out["knn_k8_c256_n3000"] = ms(lambda: knn(xf.detach(), 8))            # the default routing
+    out["knn_k8_c256_n3000_fused_mfma"] = ms(lambda: knn_fused(xf.detach(), 8))
     out["knn_k8_c256_n3000_gemm_plus_rank"] = ms(lambda: knn_unfused(xf.detach(), 8))
+    x3 = torch.rand(B, 3, 3000, generator=g).to(dev)
+    out["knn_k8_c3_n3000_fused_mfma"] = ms(lambda: knn_fused(x3, 8))
+    out["knn_k8_c3_n3000_gemm_plus_rank"] = ms(lambda: knn_unfused(x3, 8))
     nbr = knn(xf.detach(), 8)
 
     def graph_fb():

@@ -3,9 +3,9 @@
 sn_graph_feature_forward / backward (include/sparenet_hip.h).
 
 The reference's GPU branch calls the un-vendored KNN_CUDA wheel; its CPU branch ranks
--|x_i|^2 + 2 x_i.x_j - |x_j|^2 with topk.  For k <= 8 (SpareNet's EdgeConv) the whole search is ONE kernel on the fp32 matrix
+-|x_i|^2 + 2 x_i.x_j - |x_j|^2 with topk.  For k <= 8 and up to 128 channels the whole search is ONE kernel on the fp32 matrix
 cores (sn_knn, knn_mfma.hip: score tiles in the MFMA accumulators, the k best of every query in registers,
-no [B,N,N] matrix in HBM); larger k takes the inner products from one batched GEMM (torch.bmm = rocBLAS)
+no [B,N,N] matrix in HBM); wider features or larger k take the inner products from one batched GEMM (torch.bmm = rocBLAS)
 and ranks them with sn_knn_topk.  Neighbours come out ascending by distance, the point itself first,
 equal scores by lower index.
 """
@@ -16,13 +16,14 @@ import torch
 from sparenet_amd import _lib
 
 FUSED_MAX_K = 8    # sn_knn accepts k <= 20; above 8 the GEMM + ranking pair is faster (measured)
+FUSED_MAX_C = 128  # measured at B=32, N=3000: C=3 0.30 vs 0.86 ms, C=256 1.75-2.2 vs 1.77-2.0 ms, C=512 3.1 vs 2.8 ms
 
 
 def knn(x, k: int):
     """x [B, C, N] float32 on the GPU -> idx [B, N, k] int64 (indices of the k nearest points)."""
     if x.dim() != 3:
         raise ValueError("knn expects x [batch, feature_dim, num_points]")
-    return knn_fused(x, k) if k <= FUSED_MAX_K else knn_unfused(x, k)
+    return knn_fused(x, k) if k <= FUSED_MAX_K and x.shape[1] <= FUSED_MAX_C else knn_unfused(x, k)
 
 
 def knn_fused(x, k: int):
