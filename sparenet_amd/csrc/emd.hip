@@ -179,7 +179,8 @@ struct EmdWs {
   int *bid, *bid2;
   float *bid_inc;
   float *max_inc;
-  int *max_idx;
+  int *max_idx;  // GetMax's winner per target; PERSISTS across iterations like the reference's tensor
+  int *win;      // this iteration's in-window winner per target (-1: nobody was in the window)
   int *list[2];
   int *cnt[2];
   f4 *t4s;       // [B, n] by stream position p: {x, y, z, A'} of target tperm[p]
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
 struct BidOut {
   int *bid, *bid2;
   float *bid_inc, *max_inc;
-  int *max_idx;
+  int *win;
 };
 
 constexpr int kBidWaves = 16;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const
   A.bid2[o + j] = top.better_i == top.best_i ? -1 : top.better_i;
   A.bid_inc[o + j] = inc;
   atomic_max_float(&A.max_inc[o + top.best_i], inc);
-  A.max_idx[o + top.best_i] = -1;  // winner is re-derived by emd_getmax_kernel
+  A.win[o + top.best_i] = -1;  // this iteration's winner is derived by emd_getmax_kernel
 }
 
 // ---------------------------------------------------------------------------------------
@@ -753,7 +754,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
 
 __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
     int n, const int *__restrict__ bid, const float *__restrict__ bid_inc,
-    const float *__restrict__ max_inc, int *__restrict__ max_idx, const int *__restrict__ list,
+    const float *__restrict__ max_inc, int *__restrict__ win, const int *__restrict__ list,
     const int *__restrict__ cnt) {
   const int b = blockIdx.y;
   const int U = cnt[b];
@@ -764,15 +765,16 @@ __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
     const float bi = bid_inc[(size_t)b * n + j];
     const float mi = max_inc[(size_t)b * n + tgt];
     if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
-      atomicMax(&max_idx[(size_t)b * n + tgt], j);
+      atomicMax(&win[(size_t)b * n + tgt], j);
   }
 }
 
 __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
     int n, int *__restrict__ assignment, int *__restrict__ assignment_inv,
     float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
-    float *__restrict__ max_inc, const int *__restrict__ max_idx, const int *__restrict__ list,
-    const int *__restrict__ cnt, const int *__restrict__ rank1, int *__restrict__ flags,
+    float *__restrict__ max_inc, int *__restrict__ max_idx, const int *__restrict__ win,
+    const int *__restrict__ list, const int *__restrict__ cnt, const int *__restrict__ rank1,
+    int *__restrict__ flags,
     const int *__restrict__ rank2, f4 *__restrict__ t4s, float2 *__restrict__ pk, int last) {
   const int b = blockIdx.y;
   const int U = cnt[b];
@@ -784,7 +786,17 @@ __global__ __launch_bounds__(kThreads) void emd_assign_kernel(
       if (!last) flags[o + rank1[o + j]] = 1;
       continue;
     }
-    if (last || max_idx[o + tgt] == j) {
+    // GetMax only writes max_idx when some bidder's increment is within 1e-6 of max_increments, and the
+    // reference never clears that tensor (emd_cuda.cu:181-194, emd_module.py:50: zeros): when nobody is in
+    // the window -- max_increments still holds its initial 0 and every increment is negative, i.e. eps < 0 --
+    // Assign compares against the entry of an EARLIER iteration (initially 0).  Every bidder of a target
+    // sees the same `win`, so they all take the same branch: no read races a write.
+    int w = win[o + tgt];
+    if (w >= 0)
+      max_idx[o + tgt] = w;
+    else
+      w = max_idx[o + tgt];
+    if (last || w == j) {
       const int inv = assignment_inv[o + tgt];
       if (!last && inv != -1) {
         assignment[o + inv] = -1;
@@ -901,6 +913,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.bid_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_idx = reinterpret_cast<int *>(p); p += arr;
+  ws.win = reinterpret_cast<int *>(p); p += arr;
   ws.list[0] = reinterpret_cast<int *>(p); p += arr;
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
   ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
@@ -926,7 +939,7 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 15 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+  return 16 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
          2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
          2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256);
 }
@@ -960,16 +973,16 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
   for (int it = 0; it < iters; ++it) {
     const int c = it & 1;
-    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.max_idx};
+    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.win};
     // prices move by bid increments >= eps per iteration: a lower bound for every price
     const float price_floor = eps < 0.f ? eps * (float)it : 0.f;
     SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
         b, g_env, n, eps, price_floor, xyz1, ws.t4s, ws.pk, ws.rank2, ws.mstream, ws.bbox, ws.sbbox,
         ws.list[c], ws.cnt[c], bo, stats)));
-    emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
+    emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.win,
                                                     ws.list[c], ws.cnt[c]);
     emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
-                                                    ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx,
+                                                    ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx, ws.win,
                                                     ws.list[c], ws.cnt[c], ws.rank1, ws.flags,
                                                     ws.rank2, ws.t4s, ws.pk, it == iters - 1);
     if (it + 1 < iters)

@@ -78,6 +78,10 @@ def gen_emd():
         ("emd_uniform_2x1024_it50", 2, 1024, 50, 0.005, 0, "uniform"),
         ("emd_near_1x2048_it20", 1, 2048, 20, 0.005, 3, "near"),
         ("emd_uniform_1x3072_it6", 1, 3072, 6, 0.002, 5, "uniform"),
+        # eps < 0: increments below max_increments' initial 0 put nobody in GetMax's window, Assign then
+        # compares against max_idx entries of EARLIER iterations (initially 0) -- pins that the tensor persists
+        ("emd_negeps_uniform_1x1024_it3", 1, 1024, 3, -0.002, 11, "uniform"),
+        ("emd_negeps_clustered_1x1024_it3", 1, 1024, 3, -0.002, 12, "clustered"),
     ]
     for name, b, n, iters, eps, seed, kind in cases:
         g = torch.Generator().manual_seed(seed)
@@ -85,9 +89,16 @@ def gen_emd():
         if kind == "near":
             perm = torch.randperm(n, generator=g)
             y = (x + 0.01 * torch.randn(b, n, 3, generator=g))[:, perm].clamp(0, 1)
+        elif kind == "clustered":
+            c = torch.rand(b, 5, 3, generator=g)
+            pick = lambda: torch.gather(c, 1, torch.randint(0, 5, (b, n, 1), generator=g).expand(-1, -1, 3))
+            x = (pick() + 0.004 * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
+            y = (pick() + 0.004 * torch.randn(b, n, 3, generator=g)).clamp(0, 1)
         else:
             y = torch.rand(b, n, 3, generator=g)
         x, y = x.numpy(), y.numpy()
+        if os.environ.get("GEN_ONLY") and os.environ["GEN_ONLY"] not in name:
+            continue
         raw = run(exe, struct.pack("iiif", b, n, iters, eps), [x, y])
         o = 0
         dist = np.frombuffer(raw, np.float32, b * n, o).reshape(b, n); o += 4 * b * n
