@@ -51,8 +51,8 @@ PEAK_F32_TFLOPS = 157.3                                   # MI355X_MICROARCH.md 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--radius-list", type=str, default="5,7,10",
                     help="p2i radii in pixels (reference default, configs/base_config.py:56-60); "
                          "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
