@@ -35,6 +35,7 @@ from sparenet_amd.cuda.chamfer_distance import ChamferDistance, ChamferDistanceM
 from sparenet_amd.cuda.emd.emd_module import emdModule
 from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
 from sparenet_amd.cuda.MDS import MDS_module
+from sparenet_amd.cuda.knn import get_graph_feature
 
 
 class SurrogateRefine(torch.nn.Module):
@@ -220,3 +221,111 @@ class GanStep:
         return dict(rec_loss=rec_loss.detach(), errG=err_g.detach(), errG_D=err_g_d.detach(),
                     errD_real=err_d_real.detach(), errD_fake=err_d_fake.detach(),
                     coarse_loss=coarse_loss.detach() * 1000, refine_loss=refine_loss.detach() * 1000)
+
+
+class EdgeConvEncoder(torch.nn.Module):
+    """The encoder's data flow (EdgeConvResFeat, models/sparenet_generator.py:122-260) with the tensor shapes the
+    ops see: four EdgeConv stages on the 3000-point partial cloud -- k-NN graph in FEATURE space (C = 3, h/16,
+    h/16, h/8 channels, k = 8), edge features [B, 2C, N, k], a 1x1 convolution, max over the neighbours, a
+    residual 1x1 branch -- then a 1x1 convolution on the concatenated stages and global max + mean pooling.
+    Convolutions / norms run under bf16 autocast, the graph ops (sn_knn, sn_graph_feature_*) in fp32."""
+
+    def __init__(self, hide_size=4096, output_size=4096, k=8):
+        super().__init__()
+        h = hide_size
+        self.k = k
+        dims = [(6, h // 16), (h // 8, h // 16), (h // 8, h // 8), (h // 4, h // 4)]
+        self.edge = torch.nn.ModuleList(torch.nn.Conv2d(i, o, 1, bias=False) for i, o in dims)
+        self.norm = torch.nn.ModuleList(torch.nn.BatchNorm2d(o) for _, o in dims)
+        self.res = torch.nn.ModuleList([torch.nn.Conv1d(h // 16, h // 16, 1, bias=False),
+                                        torch.nn.Conv1d(h // 16, h // 8, 1, bias=False),
+                                        torch.nn.Conv1d(h // 8, h // 4, 1, bias=False)])
+        self.head = torch.nn.Conv1d(h // 2, output_size // 2, 1, bias=False)
+        self.head_norm = torch.nn.BatchNorm1d(output_size // 2)
+
+    def forward(self, x):                                   # [B, 3, N]
+        feats, cur = [], x
+        for i in range(4):
+            edges = get_graph_feature(cur.float(), k=self.k)               # fp32 HIP ops: [B, 2C, N, k]
+            with torch.autocast(x.device.type, dtype=torch.bfloat16):
+                y = torch.nn.functional.leaky_relu(self.norm[i](self.edge[i](edges)), 0.2).amax(dim=-1)
+                if i > 0:
+                    y = y + self.res[i - 1](cur)
+            cur = y
+            feats.append(y)
+        with torch.autocast(x.device.type, dtype=torch.bfloat16):
+            z = torch.nn.functional.leaky_relu(self.head_norm(self.head(torch.cat(feats, dim=1))), 0.2)
+            return torch.cat((z.amax(dim=2), z.mean(dim=2)), dim=1).float()   # [B, output_size]
+
+
+class FoldingDecoder(torch.nn.Module):
+    """A minimal stand-in for the style-based folding decoder: n_primitives 2-D grids + the global feature ->
+    [B, num_points, 3] through shared 1x1 convolutions (bf16 autocast)."""
+
+    def __init__(self, feature_size=4096, num_points=16384, n_primitives=32, width=256):
+        super().__init__()
+        self.num_points, self.n_primitives = num_points, n_primitives
+        self.proj = torch.nn.Linear(feature_size, width)
+        self.prim = torch.nn.Parameter(torch.randn(n_primitives, width) * 0.1)
+        self.net = torch.nn.Sequential(torch.nn.Conv1d(2 + width, width, 1), torch.nn.ReLU(),
+                                       torch.nn.Conv1d(width, width // 2, 1), torch.nn.ReLU(),
+                                       torch.nn.Conv1d(width // 2, 3, 1), torch.nn.Tanh())
+        per = num_points // n_primitives
+        side = int(per ** 0.5)
+        u = torch.linspace(-1, 1, side)
+        grid = torch.stack(torch.meshgrid(u, u, indexing="ij"), 0).reshape(2, -1)
+        grid = torch.nn.functional.pad(grid, (0, per - grid.shape[1]))
+        self.register_buffer("grid", grid.repeat(1, n_primitives), persistent=False)       # [2, N]
+
+    def forward(self, feature):                              # [B, F]
+        b = feature.shape[0]
+        with torch.autocast(feature.device.type, dtype=torch.bfloat16):
+            code = self.proj(feature).unsqueeze(1) + self.prim.unsqueeze(0)                # [B, P, W]
+            code = code.repeat_interleave(self.num_points // self.n_primitives, dim=1).transpose(1, 2)
+            pts = self.net(torch.cat((self.grid.unsqueeze(0).expand(b, -1, -1), code), dim=1))
+        return (0.5 * pts.float()).transpose(1, 2).contiguous()                            # [B, N, 3]
+
+
+class NetworkGenerator(torch.nn.Module):
+    """partial -> EdgeConv encoder -> folding decoder -> coarse; then the two refine stages of
+    SurrogateGenerator (expansion -> MDS -> gather) with a small residual 1x1 network each."""
+
+    def __init__(self, num_points=16384, n_primitives=32, hide_size=4096, feature_size=4096):
+        super().__init__()
+        self.encoder = EdgeConvEncoder(hide_size, feature_size)
+        self.decoder = FoldingDecoder(feature_size, num_points, n_primitives)
+        self.refine1 = ResidualRefine(num_points, n_primitives)
+        self.refine2 = ResidualRefine(num_points, n_primitives)
+
+    def forward(self, partial):                              # [B, M, 3]
+        part = partial.transpose(1, 2).contiguous()
+        coarse = self.decoder(self.encoder(part))
+        middle, loss_mst = self.refine1(coarse.transpose(1, 2).contiguous(), part, coarse)
+        refine, _ = self.refine2(middle.transpose(1, 2).contiguous(), part, middle)
+        return coarse, middle, refine, loss_mst
+
+
+class ResidualRefine(SurrogateRefine):
+    """SurrogateRefine with the offset field replaced by a small 1x1 residual network on the [B, 4, N] cloud."""
+
+    def __init__(self, num_points, n_primitives=32, width=64):
+        torch.nn.Module.__init__(self)
+        self.num_points, self.n_primitives = num_points, n_primitives
+        self.expansion = expansionPenaltyModule()
+        self.net = torch.nn.Sequential(torch.nn.Conv1d(4, width, 1), torch.nn.ReLU(),
+                                       torch.nn.Conv1d(width, width, 1), torch.nn.ReLU(),
+                                       torch.nn.Conv1d(width, 3, 1), torch.nn.Tanh())
+
+    def forward(self, inps, partial, coarse):
+        dist, _, mean_mst_dis = self.expansion(coarse, self.num_points // self.n_primitives, 1.5)
+        loss_mst = torch.mean(dist)
+        id0 = torch.zeros(inps.shape[0], 1, inps.shape[2], device=inps.device)
+        id1 = torch.ones(partial.shape[0], 1, partial.shape[2], device=partial.device)
+        base = torch.cat((torch.cat((inps, id0), 1), torch.cat((partial, id1), 1)), 2)   # [B,4,N+M]
+        idx = MDS_module.minimum_density_sample(base[:, 0:3, :].transpose(1, 2).contiguous(),
+                                                coarse.shape[1], mean_mst_dis)
+        base = MDS_module.gather_operation(base.contiguous(), idx)
+        with torch.autocast(base.device.type, dtype=torch.bfloat16):
+            delta = self.net(base)
+        outs = base[:, 0:3, :] + 0.05 * delta.float()
+        return outs.transpose(2, 1).contiguous(), loss_mst

@@ -3,7 +3,7 @@ B=32, 16384 output points, 3000 input points, n_primitives 32."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from sparenet_amd.harness import Completion, GanStep, SurrogateDiscriminator, SurrogateGenerator
+from sparenet_amd.harness import Completion, GanStep, NetworkGenerator, SurrogateDiscriminator, SurrogateGenerator
 
 dev = torch.device("cuda:0")
 B, N, M = 32, 16384, 3000
@@ -44,3 +44,20 @@ for _ in range(K): out = gan(part_d, gt_d)
 torch.cuda.synchronize()
 print(f"gan step (chamfer metric): {(time.perf_counter() - t0) / K * 1e3:.1f} ms "
       f"(errG {float(out['errG']):.4f} errD {float(out['errD_real'] + out['errD_fake']):.4f})")
+
+# the same reconstruction step with networks in it: EdgeConv encoder at the reference's widths (hide 4096: k-NN
+# graphs on 3 / 256 / 256 / 512 channels, k = 8), folding decoder, residual refiners; bf16 autocast
+torch.manual_seed(0)
+net = NetworkGenerator(num_points=N, n_primitives=32, hide_size=4096, feature_size=4096).to(dev)
+comp = Completion("chamfer").to(dev)
+opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+def nstep():
+    loss, *_ = comp(net, part_d, gt_d)
+    opt.zero_grad(); loss.backward(); opt.step()
+    return loss
+nstep(); torch.cuda.synchronize()
+t0 = time.perf_counter(); K = 3
+for _ in range(K): last = nstep()
+torch.cuda.synchronize()
+print(f"network generator (EdgeConv encoder + decoder + refiners, bf16), chamfer metric: "
+      f"{(time.perf_counter() - t0) / K * 1e3:.1f} ms per step, peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
