@@ -343,6 +343,13 @@ struct GatherHit {
   unsigned low;     // 0xFFFFFFFE - point id
 };
 
+#ifdef SN_P2I_DIAG  // survivor statistics of the gather (diag build only)
+__device__ unsigned long long g_gather_diag[8];
+#define GDIAG(...) __VA_ARGS__
+#else
+#define GDIAG(...)
+#endif
+
 // C1 = single-channel features (ComputeDepthMaps): the feature travels in the sorted record.  As a run-time
 // test the per-channel load sat in a branch next to the record prefetch and hipcc covered both with one
 // s_waitcnt vmcnt(0) -- every batch of 64 candidates waited for the NEXT batch's records to arrive.
@@ -382,6 +389,7 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
               ty1 = ty0 + (kCell - 1);
   float tile_min[NR];  // wave-uniform: smallest current best over the tile's pixels
   int qn = 0;  // wave-uniform queue fill
+  GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_survk = 0, dg_evalk = 0, dg_hits = 0, dg_hitc = 0;)
   auto refresh_tile_min = [&]() {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
@@ -457,6 +465,8 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
       unsigned long long todo = keep[0];
 #pragma unroll
       for (int k = 1; k < NR; ++k) todo |= keep[k];
+      GDIAG(dg_batches++; dg_cand += (end - base < 64 ? end - base : 64); dg_surv += __popcll(todo);
+            for (int k = 0; k < NR; ++k) dg_survk += __popcll(keep[k]);)
       while (todo) {  // wave-uniform: candidate i broadcast to every pixel
         const int i = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -476,6 +486,7 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
           const float ub = f * __builtin_fmaxf(wq, 0.f);
           const bool pass = ink && ub >= best[k];  // can still reach (or tie with) the best
           const unsigned long long m = __ballot(pass);
+          GDIAG(dg_evalk++; dg_hits += __popcll(m); dg_hitc += m ? 1 : 0;)
           if (m) {
             if (pass)
               q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
@@ -498,6 +509,12 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
     }
   }
   if (qn > 0) drain(0, qn);
+  GDIAG(if (lane == 0) {
+    atomicAdd(&g_gather_diag[0], 1ull); atomicAdd(&g_gather_diag[1], (unsigned long long)dg_batches);
+    atomicAdd(&g_gather_diag[2], (unsigned long long)dg_cand); atomicAdd(&g_gather_diag[3], (unsigned long long)dg_surv);
+    atomicAdd(&g_gather_diag[4], (unsigned long long)dg_survk); atomicAdd(&g_gather_diag[5], (unsigned long long)dg_evalk);
+    atomicAdd(&g_gather_diag[6], (unsigned long long)dg_hits); atomicAdd(&g_gather_diag[7], (unsigned long long)dg_hitc);
+  })
   if (valid) {
     const size_t image = (size_t)batch * channels * h * w;  // one output tensor per radius
 #pragma unroll
@@ -962,6 +979,17 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
 }
 
 }  // namespace
+
+#ifdef SN_P2I_DIAG
+extern "C" int sn_p2i_gather_diag(unsigned long long *out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_gather_diag), 64) != hipSuccess) return 1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_gather_diag), z, 64) != hipSuccess) return 1;
+  }
+  return 0;
+}
+#endif
 
 extern "C" size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels, int h,
                                                    int w) {
