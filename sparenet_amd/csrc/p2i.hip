@@ -31,6 +31,8 @@ __device__ __forceinline__ unsigned ord_f32(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ unsigned umin_u32(unsigned a, unsigned b) { return a < b ? a : b; }
+
 __device__ __forceinline__ float unord_f32(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
@@ -390,12 +392,19 @@ __global__ __launch_bounds__(256) void p2i_gather_max_kernel(
   float tile_min[NR];  // wave-uniform: smallest current best over the tile's pixels
   int qn = 0;  // wave-uniform queue fill
   GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_survk = 0, dg_evalk = 0, dg_hits = 0, dg_hitc = 0;)
+  // wave minimum on the order-preserving bit patterns the slots hold anyway: four DPP v_min_u32 steps and
+  // four readlanes per radius (the float butterfly was six ds_bpermute + min + canonicalising max each)
   auto refresh_tile_min = [&]() {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      float m = valid ? best[k] : 3.0e38f;
-      for (int sft = 1; sft < 64; sft <<= 1) m = __builtin_fminf(m, __shfl_xor(m, sft));
-      tile_min[k] = m;
+      unsigned m = valid ? ord_f32(best[k]) : 0xffffffffu;
+      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
+      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
+      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x141, 0xf, 0xf, true));  // row_half_mirror
+      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x140, 0xf, 0xf, true));  // row_mirror
+      const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b2 = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
+      const unsigned c2 = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d2 = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
+      tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2), umin_u32(c2, d2)));
     }
   };
   refresh_tile_min();
