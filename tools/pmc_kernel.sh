@@ -19,7 +19,11 @@ for d in ("pmc1", "pmc2"):
         if "$K" not in r["Kernel_Name"]:
             continue
         agg.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
-    for did in sorted(agg)[:3]:
-        print(d, did, {k: f"{v:.4g}" for k, v in agg[did].items()})
+    ids = sorted(agg)
+    for did in ids[:2]:
+        print(d, "dispatch", did, {k: f"{v:.4g}" for k, v in agg[did].items()})
+    tail = ids[-20:]   # e.g. the late auction iterations
+    keys = sorted(agg[tail[0]])
+    print(d, f"mean of the last {len(tail)} dispatches", {k: f"{sum(agg[i].get(k, 0.0) for i in tail) / len(tail):.4g}" for k in keys})
 PY
 rm -rf gpurun_out/pmc1 gpurun_out/pmc2
