@@ -356,7 +356,7 @@ __device__ unsigned long long g_gather_diag[8];
 // test the per-channel load sat in a branch next to the record prefetch and hipcc covered both with one
 // s_waitcnt vmcnt(0) -- every batch of 64 candidates waited for the NEXT batch's records to arrive.
 template <int NR, bool C1>
-__global__ __launch_bounds__(256) void p2i_gather_max_kernel(
+__global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     const float *__restrict__ feat, const float *__restrict__ background,
     const float4 *__restrict__ srec, const int *__restrict__ offs,
     int channels, int batch, int h, int w, int cells_x, int cells_y, RadiiArg ra,
