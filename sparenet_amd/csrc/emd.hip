@@ -611,10 +611,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
       refresh_reach();
       const f4 *ms = mstream + (size_t)b * nsb * 64 + lane;
       const float *sbb = sbbox + (size_t)b * nsb * 32;
-      // bit g: block `blk` of 16 targets can hold a hit for a bidder of subgroup g
-      auto worth = [&](int blk) {
-        const f4 lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)blk * 8);
-        const f4 hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)blk * 8 + 4);
+      // bit g: the block of 16 targets whose box is (lo4, hi4) can hold a hit for a bidder of subgroup g.
+      // The box stays in the lane's registers for the whole pass: the re-evaluation after every drain used
+      // to load it again (two dependent-free but cold global reads, ~1 us each time).
+      auto worth = [&](const f4 lo4, const f4 hi4) {
         unsigned m = 0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -641,7 +641,12 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
         const int sbl = (task >> 2) * S + seg;
         const bool mine = task < owned4;
         DIAG(const long long dg_w0 = __builtin_amdgcn_s_memrealtime();)
-        unsigned gmask = quad_mask(mine ? worth(sbl * 4 + (task & 3)) : 0u);
+        f4 box_lo = {0.f, 0.f, 0.f, 0.f}, box_hi = {0.f, 0.f, 0.f, 0.f};
+        if (mine) {
+          box_lo = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8);
+          box_hi = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8 + 4);
+        }
+        unsigned gmask = quad_mask(mine ? worth(box_lo, box_hi) : 0u);
         unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
         DIAG(dg_worth += __builtin_amdgcn_s_memrealtime() - dg_w0;)
         f4 a_next = {0.f, 0.f, 0.f, 0.f};
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
             refresh_reach();
             if (todo) {
               const bool left = (todo >> (lane & ~3)) & 1ull;
-              gmask = quad_mask(left ? worth(sbl * 4 + (task & 3)) : 0u);
+              gmask = quad_mask(left ? worth(box_lo, box_hi) : 0u);
               todo = __ballot(gmask != 0u && (lane & 3) == 0);
             }
           }
