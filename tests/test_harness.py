@@ -93,3 +93,18 @@ def test_network_generator_step(dev):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses), losses
+
+
+def test_surrogate_network_shapes_on_cpu():
+    """Host-side pieces of the harness that need no GPU: the folding decoder and the discriminator keep the
+    tensor shapes the step relies on (bf16 autocast also exists on the CPU)."""
+    from sparenet_amd.harness import FoldingDecoder, SurrogateDiscriminator
+
+    dec = FoldingDecoder(feature_size=32, num_points=1024, n_primitives=4, width=16)
+    cloud = dec(torch.rand(3, 32))
+    assert cloud.shape == (3, 1024, 3) and cloud.dtype == torch.float32 and torch.isfinite(cloud).all()
+    assert float(cloud.abs().max()) <= 0.5 + 1e-6                      # tanh / 2: inside the renderer's cube
+    disc = SurrogateDiscriminator((16, 64, 64))
+    val, feats = disc(torch.rand(2, 16, 64, 64), feat=True)
+    assert val.shape == (2, 1) and [tuple(f.shape[1:]) for f in feats] == [(16, 32, 32), (32, 16, 16), (64, 8, 8), (128, 4, 4)]
+    assert disc(torch.rand(2, 16, 64, 64)).shape == (2, 1)
