@@ -174,3 +174,23 @@ def test_hip_full_size_sparenet_shape(golden_dir, dev):
     z = np.load(os.path.join(golden_dir, "mds_1x19384_m1024.npz"))
     idx = oracle.mds(z["xyz"], int(z["npoint"]), z["mean_mst_length"], exp_mode=0, bs_override=1)
     assert np.array_equal(idx, z["idx_bs1"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,mml", [("sphere", 0.010), ("patches", 0.015)])
+def test_hip_full_length_on_surface_clouds(kind, mml, dev):
+    """All 16384 picks of a 19384-point SURFACE cloud (SpareNet's refine stage) against the oracle: late in
+    such a run every region already holds picks, which is where the absorption culling (an increment below
+    half an ulp of every density of a slot is skipped) prunes most -- it must never change a pick."""
+    rng = np.random.default_rng(5)
+    n, m = 19384, 16384
+    if kind == "sphere":
+        v = rng.standard_normal((1, n, 3)).astype(np.float32)
+        x = (0.5 * v / np.linalg.norm(v, axis=2, keepdims=True)).astype(np.float32)
+    else:
+        c = rng.standard_normal((1, 32, 3)).astype(np.float32)
+        c = 0.5 * c / np.linalg.norm(c, axis=2, keepdims=True)
+        pick = np.take_along_axis(c, rng.integers(0, 32, (1, n, 1)).repeat(3, 2), 1)
+        x = (pick + 0.03 * rng.standard_normal((1, n, 3)).astype(np.float32)).astype(np.float32)
+    mm = np.array([mml], np.float32)
+    assert np.array_equal(_hip_mds(x, m, mm, dev), oracle.mds(x, m, mm, exp_mode=1))
