@@ -831,8 +831,8 @@ __global__ __launch_bounds__(1024) void emd_compact_kernel(int n, const int *__r
   const int b = blockIdx.x, tid = threadIdx.x;
   const size_t o = (size_t)b * n;
   // rank r = 4 (1024 i + tid) + e: every pass reads one coalesced int4 per lane
-  const int passes = n / 4096 > 0 ? n / 4096 : 1;  // n is a multiple of 1024
-  const int vec = n / 4;                            // int4 words per cloud
+  const int vec = n / 4;                // int4 words per cloud (n is a multiple of 1024)
+  const int passes = (vec + 1023) / 1024;  // ceil: n = 5120, 6144, ... need the partial last pass
   int base = 0;
   for (int i = 0; i < passes; ++i) {
     const int w = i * 1024 + tid;

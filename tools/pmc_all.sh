@@ -1,0 +1,48 @@
+#!/bin/bash
+# usage (on the GPU box): tools/pmc_all.sh <out.json> [probe script, default tools/step_probe.py]
+# Hardware counters of every hot kernel: four rocprofv3 passes (counters only: --kernel-trace + --pmc,
+# never combined with other trace domains), per-kernel means written to <out.json>.
+#   pass A: wave / VALU / wait counters       pass B: LDS, VMEM, MFMA, any-instruction activity
+#   pass C: FETCH_SIZE (+ GRBM_GUI_ACTIVE)    pass D: WRITE_SIZE
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$1; shift
+PROBE=${1:-tools/step_probe.py}
+cd /tmp
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU --output-format csv -d $R/gpurun_out/pmcA -- python $R/$PROBE > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $R/gpurun_out/pmcB -- python $R/$PROBE > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/pmcC -- python $R/$PROBE > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmcD -- python $R/$PROBE > /dev/null 2>&1
+cd $R
+python - "$OUT" <<'PY'
+import csv, glob, json, subprocess, sys
+kernels = ["emd_bid_kernel", "emd_auction_kernel", "emd_assign_kernel", "emd_compact_kernel", "emd_getmax_kernel",
+           "nn_search_kernel", "chamfer_bwd_scatter_kernel", "chamfer_bwd_own_kernel", "expansion_fwd_kernel",
+           "p2i_gather_max_kernel", "p2i_max_bwd_accum_kernel", "p2i_bin_scatter_kernel", "mds_clustered_kernel"]
+res = {k: {} for k in kernels}
+for d in ("pmcA", "pmcB", "pmcC", "pmcD"):
+    fs = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)
+    if not fs:
+        res.setdefault("_missing", []).append(d)
+        continue
+    agg = {}
+    for r in csv.DictReader(open(fs[0])):
+        for k in kernels:
+            if k in r["Kernel_Name"]:
+                a = agg.setdefault((k, r["Counter_Name"]), {})
+                a[int(r["Dispatch_Id"])] = a.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+                break
+    for (k, c), per in agg.items():
+        v = list(per.values())
+        res[k][c] = {"mean": sum(v) / len(v), "max": max(v), "min": min(v), "dispatches": len(v)}
+res = {k: v for k, v in res.items() if v}
+try:
+    res["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
+except Exception:
+    pass
+json.dump(res, open(sys.argv[1], "w"), indent=1)
+for k, v in res.items():
+    if isinstance(v, dict):
+        print(k, {c: f"{x['mean']:.4g}" for c, x in v.items()})
+PY
+rm -rf gpurun_out/pmcA gpurun_out/pmcB gpurun_out/pmcC gpurun_out/pmcD

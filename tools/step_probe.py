@@ -1,0 +1,50 @@
+"""One pass of every hot op at the benched sizes, for profiler passes (tools/pmc_all.sh, tools/kstats.sh).
+Env: PROBE_MDS=0 skips the sampler, PROBE_VIEWS (default 2) renderer views."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import sparenet_amd._lib as _L
+if os.environ.get("AB_LIB"):
+    _L.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
+from sparenet_amd.cuda.chamfer_distance import ChamferDistance
+from sparenet_amd.cuda.emd.emd_module import emdModule
+from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
+from sparenet_amd.cuda.MDS.MDS_module import minimum_density_sample
+from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
+
+dev = torch.device("cuda:0")
+B, N = 32, 16384
+g = torch.Generator().manual_seed(1234)
+pred = torch.rand(B, N, 3, generator=g).to(dev)
+gt = torch.rand(B, N, 3, generator=g).to(dev)
+render = ComputeDepthMaps("orthorgonal", 1.0, 256).to(dev)
+for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
+    p = pred.clone().requires_grad_(True)
+    pen, _, mml = expansionPenaltyModule()(p, 512, 1.5)
+    pen.mean().backward()
+    p = pred.clone().requires_grad_(True)
+    q = gt.clone().requires_grad_(True)
+    d1, d2 = ChamferDistance()(p, q)
+    (d1.mean() + d2.mean()).backward()
+    p = pred.clone().requires_grad_(True)
+    dist, _ = emdModule()(p, gt, 0.005, 50)
+    torch.sqrt(dist).mean().backward()
+    p4 = (pred - 0.5).requires_grad_(True)
+    acc = 0
+    for v in range(int(os.environ.get("PROBE_VIEWS", "2"))):
+        acc = acc + render(p4, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
+    acc.backward()
+    torch.cuda.synchronize()
+if os.environ.get("PROBE_MDS", "1") != "0":
+    v = torch.randn(B, N, 3, generator=g)
+    v = 0.5 * v / v.norm(dim=2, keepdim=True)
+    key = (torch.atan2(v[..., 1], v[..., 0]) * 4).floor() * 100 + (v[..., 2] * 8).floor()
+    surf = torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous().to(dev)
+    _, _, mml_s = expansionPenaltyModule()(surf, 512, 1.5)
+    cloud_s = torch.cat([surf, surf[:, :3000] + 0.01 * torch.randn(B, 3000, 3, generator=g).to(dev)], 1).contiguous()
+    minimum_density_sample(cloud_s, N, mml_s)
+    torch.cuda.synchronize()
+print("probe done")
