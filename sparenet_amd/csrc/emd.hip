@@ -30,6 +30,8 @@
 //     S = 2^k <= 64 waves share one group of 64 bidders, each scanning n/S targets; up to
 //     16 of them merge in LDS, the rest through emd_bid_finish_kernel.
 //   * GetMax: deterministic atomicMax of the bidder index inside the window.
+#include <cstdlib>
+
 #include "cloud_sort.hpp"
 #include "common.hpp"
 
@@ -197,10 +199,11 @@ struct EmdWs {
   int *flags;    // [B, n] by rank: unassigned after this iteration (next list = flagged ranks in order)
   int *hist1;    // [B, 4096] sort scratch of the bidders
   float *bbox1;  // [B, 6]
+  void *ctl;     // persistent auction: ticket, abort word, one barrier counter per team
 };
 
 __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
-                                int *__restrict__ assignment, EmdWs ws) {
+                                int *__restrict__ assignment, EmdWs ws, int flag_init) {
 #pragma clang fp contract(off)
   const long total = (long)B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -214,7 +217,7 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.bid2[e] = -1;
     ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
     ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
-    ws.flags[e] = 0;
+    ws.flags[e] = flag_init;  // persistent auction: every bidder starts flagged (= unassigned)
     {  // stream position p of this cloud holds target k = tperm[p]
       const long bb = e / n;
       const int p = (int)(e - bb * n);
@@ -757,6 +760,560 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
   }
 }
 
+
+// =======================================================================================
+// Persistent auction: ALL iterations of a call in ONE launch.
+//
+// The launch-per-phase form above pays, per iteration, four kernel boundaries, four grids that start with
+// cold L1/L2 and three small kernels of 5-13 us each: in the 40 late iterations (a few hundred bidders per
+// cloud) that is two thirds of the time.  Here a TEAM of G workgroups owns a cloud for the whole call and
+// walks  compact -> bid -> [barrier] -> getmax -> [barrier] -> assign -> [barrier]  with a team barrier
+// (monotonic counter, agent-scope release / acquire: placement independent) between the phases.
+//   * Workgroup m of a team owns the Morton RANKS [m n/G, (m+1) n/G) of the bidders for the whole call:
+//     it compacts its own raised flags into a local list (no global scan), bids for those bidders, runs
+//     their GetMax / Assign steps.  Its bidders stay spatial neighbours, and the targets near them stay in
+//     its L1 / the team's L2 from one iteration to the next.  The order in which bidders are served never
+//     enters a result (top-2 values, tie keys, atomicMax winners), so this is bit-identical.
+//   * S = 2^k <= 16 waves share one local group of 64 bidders exactly as above.
+//   * The unassigned count of the next iteration (the reference's tie geometry needs it) is accumulated
+//     with one atomic per wave while Assign raises the flags.
+//   * Teams are formed from a TICKET taken at start, not from blockIdx: a workgroup only ever waits for
+//     workgroups that have started, and at most one block of teams per launch is incomplete at any time,
+//     so concurrent launches on other streams cannot starve each other (each can hold <= 63 CUs waiting).
+//     With >= 32 clouds a team is the 8 tickets of one residue class mod 8 inside a block of 64 -- one XCD
+//     under the observed round-robin placement (speed only); fewer clouds get larger, contiguous teams.
+//   * Every spin is bounded; a timeout raises ctl.abort, every workgroup of the launch leaves, and
+//     sn_emd_forward reports it on the next call that checks (SN_EMD_CHECK=1: immediately).
+// =======================================================================================
+struct AuctionCtl {  // zeroed by a memset node before every launch
+  unsigned ticket;
+  unsigned abort;
+  unsigned pad[30];
+  unsigned bar[1];  // [teams * 32]: one counter per team, 128 bytes apart
+};
+
+struct TeamGeom {
+  int G;       // workgroups per team (power of two)
+  int teams;   // teams in the launch
+  int xcd;     // 1: teams are residue classes mod 8 inside blocks of 8 G tickets
+};
+
+__host__ __device__ inline TeamGeom team_geometry(int B, int W) {
+  TeamGeom t;
+  if (B >= 32 && W >= 64) {
+    // one XCD's share of a block of 64 tickets per team; more clouds than teams: halve the teams' size
+    // until every cloud has its own team (teams of one workgroup serve several clouds in turn)
+    int g = 8;
+    while (g > 1 && (W / (8 * g)) * 8 < B) g >>= 1;
+    t.G = g;
+    t.teams = (W / (8 * g)) * 8;
+    t.xcd = 1;
+  } else {
+    int g = 1;
+    while (g < 64 && g * 2 * B <= W) g *= 2;
+    t.G = g;
+    t.teams = W / g > 0 ? W / g : 1;
+    t.xcd = 0;
+  }
+  return t;
+}
+
+constexpr unsigned kSpinLimit = 40u * 1000u * 1000u;  // x ~64 ns: > 2 s
+
+struct TeamSync {
+  unsigned *bar;     // the team's counter
+  unsigned *abort;   // the launch's abort word
+  unsigned target;   // arrivals expected at the next barrier
+  int G;
+};
+
+// all waves of all G workgroups arrive; everything written before is visible to plain loads after
+__device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  ts.target += (unsigned)ts.G;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(ts.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (__hip_atomic_load(ts.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ts.target) {
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 255u) == 0u) {
+        if (__hip_atomic_load(ts.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
+        if (spins > kSpinLimit) {
+          __hip_atomic_store(ts.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+struct BidCtx {
+  int n, nsb;
+  float eps, a_max, tmax;
+  TieGeom geom;
+  size_t o;
+  const float *p1;   // bidders of this cloud
+  const f4 *t4;      // by stream position; prices inside change between the phases (no __restrict__)
+  const float2 *pkc;
+  const int *rk2;
+  const f4 *ms;      // MFMA operand stream of this cloud
+  const float *sbb;  // block boxes of this cloud
+  BidOut A;
+};
+
+// One group of 64 bidders, seen by one of its S segment-waves: the body of emd_bid_kernel's work item
+// (same filters, same queue, same exact path) with the bidder list given as a pointer.
+__device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc &ga, const int *lst,
+                                          int count, int grp, int ngroups, int S, int seg, int lane) {
+  const int row = lane >> 4, col = lane & 15;
+  const int u = grp * 64 + lane;
+  const bool active = grp < ngroups && u < count;
+  const float a_max = c.a_max, tmax = c.tmax;
+  const TieGeom geom = c.geom;
+  const f4 *t4 = c.t4;
+  const float2 *pkc = c.pkc;
+  Top2 top = {-1e9f, -1e9f, -1, -1};
+  int j = 0;
+  if (grp < ngroups) {  // wave-uniform
+    j = lst[active ? u : grp * 64];
+    float blo[4][3], bhi[4][3];
+    float own_slack2;
+    {
+      const float x1 = c.p1[j * 3 + 0], y1 = c.p1[j * 3 + 1], z1 = c.p1[j * 3 + 2];
+      {
+#pragma clang fp contract(off)
+        const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
+        own_slack2 = 2.f * 3.814697265625e-06f * (tmax + xx);
+        const float v[3] = {x1, y1, z1};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const float lo = row16_min(active ? v[a] : 3.0e38f), hi = row16_max(active ? v[a] : -3.0e38f);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            blo[g][a] = lane_value(lo, 16 * g);
+            bhi[g][a] = lane_value(hi, 16 * g);
+          }
+        }
+      }
+      float cm = -1e9f;
+      const int pa = c.A.bid[c.o + j], pb = c.A.bid2[c.o + j];
+      if (pa >= 0 && pb >= 0) {
+        const int qa = c.rk2[pa], qb = c.rk2[pb];
+        const f4 ta = t4[qa], tb = t4[qb];
+        const float da = bid_value(ta.x, ta.y, ta.z, pkc[qa].x, x1, y1, z1);
+        const float db = bid_value(tb.x, tb.y, tb.z, pkc[qb].x, x1, y1, z1);
+        cm = __builtin_fminf(da, db);
+      }
+      T.x[lane] = x1;
+      T.y[lane] = y1;
+      T.z[lane] = z1;
+      T.cm[lane] = active ? cm : 3.0e38f;
+      T.best[lane] = -1e9f;
+      T.better[lane] = -1e9f;
+      T.bi[lane] = -1;
+      T.bi2[lane] = -1;
+    }
+    float thr[4], base[4], bop[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma clang fp contract(off)
+      const int cc = 16 * g + col;
+      const float x = T.x[cc], y = T.y[cc], z = T.z[cc];
+      const float xx = (x * x + y * y) + z * z;
+      base[g] = 3.814697265625e-06f * (tmax + xx) - xx;
+      thr[g] = coarse_threshold(T.cm[cc], base[g], a_max);
+      bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
+    }
+    int qcount = 0;
+
+    auto batch = [&](int first, int cnt) {
+      const bool on = lane < cnt;
+      const unsigned e = T.queue[first + (on ? lane : 0)];
+      const int cc = (int)(e >> 20);
+      const f4 t = t4[e & 0xfffffu];
+      const float2 pq = pkc[e & 0xfffffu];
+      const int k = __float_as_int(pq.y);
+      const float sq = sq_dist(t.x, t.y, t.z, T.x[cc], T.y[cc], T.z[cc]);
+      bool pend = on && filter_pass(sq, t.w, filter_thr(T.cm[cc]));
+      float d = 0.f;
+      if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pq.x);
+      volatile int *own = T.owner;
+      while (__any(pend)) {
+        asm volatile("" ::: "memory");
+        if (pend) own[cc] = lane;
+        if (pend && own[cc] == lane) {
+          Top2 tp = {T.best[cc], T.better[cc], T.bi[cc], T.bi2[cc]};
+          top2_push(tp, d, k, geom);
+          T.best[cc] = tp.best;
+          T.better[cc] = tp.better;
+          T.bi[cc] = tp.best_i;
+          T.bi2[cc] = tp.better_i;
+          T.cm[cc] = __builtin_fmaxf(T.cm[cc], tp.better);
+          pend = false;
+        }
+      }
+      asm volatile("" ::: "memory");
+    };
+
+    float r2g[4];
+    auto refresh_reach = [&]() {
+      const float v = row16_max(active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float r = lane_value(v, 16 * g);
+        r2g[g] = r > 0.f ? r * 1.0001f : r;
+      }
+    };
+    refresh_reach();
+    const f4 *ms = c.ms + lane;
+    const float *sbb = c.sbb;
+    auto worth = [&](const f4 lo4, const f4 hi4) {
+      unsigned m = 0;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float gx = __builtin_fmaxf(__builtin_fmaxf(lo4.x - bhi[g][0], blo[g][0] - lo4.w), 0.f);
+        const float gy = __builtin_fmaxf(__builtin_fmaxf(lo4.y - bhi[g][1], blo[g][1] - hi4.x), 0.f);
+        const float gz = __builtin_fmaxf(__builtin_fmaxf(lo4.z - bhi[g][2], blo[g][2] - hi4.y), 0.f);
+        m |= (((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2g[g] ? 1u : 0u) << g;
+      }
+      return m;
+    };
+    auto quad_mask = [&](unsigned m) {
+      const unsigned m0 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x00, 0xf, 0xf, true);
+      const unsigned m1 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x55, 0xf, 0xf, true);
+      const unsigned m2 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xAA, 0xf, 0xf, true);
+      const unsigned m3 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xFF, 0xf, 0xf, true);
+      return m0 | (m1 << 4) | (m2 << 8) | (m3 << 12);
+    };
+    const int owned4 = (c.nsb / S) * 4;
+    for (int t0 = 0; t0 < owned4; t0 += 64) {
+      const int task = t0 + lane;
+      const int sbl = (task >> 2) * S + seg;
+      const bool mine = task < owned4;
+      f4 box_lo = {0.f, 0.f, 0.f, 0.f}, box_hi = {0.f, 0.f, 0.f, 0.f};
+      if (mine) {
+        box_lo = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8);
+        box_hi = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8 + 4);
+      }
+      unsigned gmask = quad_mask(mine ? worth(box_lo, box_hi) : 0u);
+      unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
+      f4 a_next = {0.f, 0.f, 0.f, 0.f};
+      int next_sb = -1;
+      while (todo) {
+        const int tl = __builtin_ctzll(todo);
+        const int sb = ((t0 + tl) >> 2) * S + seg;
+        todo &= todo - 1;
+        const int kb = sb * 64;
+        const f4 a = sb == next_sb ? a_next : ms[(size_t)sb * 64];
+        if (todo) {
+          next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
+          a_next = ms[(size_t)next_sb * 64];
+        }
+        bool drained = false;
+        const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, tl);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          if (!(gm & (0x1111u << g))) continue;
+          const f4 zero = {0.f, 0.f, 0.f, 0.f};
+          const f4 far = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
+          const f4 d0 = (gm >> g) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0) : far;
+          const f4 d1 = (gm >> (4 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0) : far;
+          const f4 d2 = (gm >> (8 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0) : far;
+          const f4 d3 = (gm >> (12 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0) : far;
+          if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
+            unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
+                          hits4(d3, thr[g], 12);
+            while (__any(hm != 0)) {
+              const bool has = hm != 0;
+              const int i = has ? __builtin_ctz(hm) : 0;
+              hm &= hm - 1;
+              const unsigned long long bal = __ballot(has);
+              const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
+                                           (unsigned)(bal >> 32),
+                                           __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+              if (has)
+                T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
+                               ((unsigned)(16 * g + col) << 20);
+              qcount += __popcll(bal);
+              while (qcount >= 64) {
+                qcount -= 64;
+                batch(qcount, 64);
+                drained = true;
+              }
+            }
+          }
+        }
+        if (drained) {
+#pragma unroll
+          for (int gg = 0; gg < 4; ++gg)
+            thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
+          refresh_reach();
+          if (todo) {
+            const bool left = (todo >> (lane & ~3)) & 1ull;
+            gmask = quad_mask(left ? worth(box_lo, box_hi) : 0u);
+            todo = __ballot(gmask != 0u && (lane & 3) == 0);
+          }
+        }
+      }
+    }
+    if (qcount > 0) batch(0, qcount);
+    top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
+  }
+  bool emit = seg == 0;
+  if (S > 1 && grp < ngroups) {
+    if (lane == 0)
+      while (atomicCAS(&ga.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const int arrived = ga.arrived;
+    if (arrived > 0)
+      top2_merge(top, ga.best[lane], ga.better[lane], ga.bi[lane], ga.bi2[lane], geom);
+    emit = arrived == S - 1;
+    if (!emit) {
+      ga.best[lane] = top.best;
+      ga.better[lane] = top.better;
+      ga.bi[lane] = top.best_i;
+      ga.bi2[lane] = top.better_i;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) {
+      ga.arrived = emit ? 0 : arrived + 1;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      atomicExch(&ga.lock, 0);
+    }
+  }
+  if (emit && active) emit_bid(c.A, c.o, j, top, c.eps);
+}
+
+struct AuctionArgs {
+  int B, n, iters;
+  float eps;
+  const float *xyz1, *xyz2;
+  int *assignment;
+  float *dist;
+  EmdWs ws;
+  AuctionCtl *ctl;
+  long long *stats;
+  TeamGeom tg;
+};
+
+__global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs a) {
+  __shared__ WaveTab tabs[kBidWaves];
+  __shared__ GroupAcc gacc[kBidWaves];
+  __shared__ int wsum[kBidWaves];
+  __shared__ int s_flag, s_ticket;
+  const int tid = threadIdx.x;
+  if (tid < kBidWaves) {
+    gacc[tid].lock = 0;
+    gacc[tid].arrived = 0;
+  }
+  if (tid == 0)
+    s_ticket = (int)__hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const int ticket = s_ticket;
+  const int G = a.tg.G;
+  int team, m;
+  if (a.tg.xcd) {  // blocks of 8 G tickets: residue class mod 8 = team inside the block
+    const int blk = ticket / (8 * G), r = ticket % (8 * G);
+    team = blk * 8 + (r & 7);
+    m = r >> 3;
+  } else {
+    team = ticket / G;
+    m = ticket % G;
+  }
+  if (team >= a.tg.teams) return;  // surplus workgroups of a grid that is no multiple of the team size
+  TeamSync ts = {a.ctl->bar + (size_t)team * 32, &a.ctl->abort, 0u, G};
+
+  const int n = a.n, nsb = n >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int R = n / G;          // ranks owned by this workgroup (n % 1024 == 0, G <= 64: a multiple of 16)
+  const int r0 = m * R;
+  const int block_cnt = n / 1024;
+  float *price = a.ws.price;
+  int *flags = a.ws.flags;
+  int *llist_all = a.ws.list[0];
+  const BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.bid_inc, a.ws.max_inc, a.ws.win};
+
+  for (int b = team; b < a.B; b += a.tg.teams) {
+    const size_t o = (size_t)b * n;
+    int *llist = llist_all + o + r0;
+    float tmax = 0.f;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const float lo = a.ws.bbox[b * 6 + ax], hi = a.ws.bbox[b * 6 + 3 + ax];
+      tmax += __builtin_fmaxf(lo * lo, hi * hi);
+    }
+    tmax *= 1.0001f;
+    BidCtx c;
+    c.n = n;
+    c.nsb = nsb;
+    c.eps = a.eps;
+    c.tmax = tmax;
+    c.o = o;
+    c.p1 = a.xyz1 + o * 3;
+    c.t4 = a.ws.t4s + o;
+    c.pkc = a.ws.pk + o;
+    c.rk2 = a.ws.rank2 + o;
+    c.ms = a.ws.mstream + (size_t)b * nsb * 64;
+    c.sbb = a.ws.sbbox + (size_t)b * nsb * 32;
+    c.A = bo;
+
+    for (int it = 0; it < a.iters; ++it) {
+      const int cur = it & 1;
+      // unassigned bidders of the cloud: n in the first iteration, afterwards what Assign counted
+      const int U = it == 0 ? n
+                            : (int)__hip_atomic_load(reinterpret_cast<unsigned *>(a.ws.cnt[cur] + b),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (U == 0) break;  // every workgroup of the team reads the same value
+      const bool last = it == a.iters - 1;
+      if (m == 0 && tid == 0) {
+        if (a.stats) {
+          atomicAdd(reinterpret_cast<unsigned long long *>(a.stats), (unsigned long long)U * n);
+          if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
+        }
+        // the counter Assign fills in this iteration (read last at the top of the previous one)
+        __hip_atomic_store(reinterpret_cast<unsigned *>(a.ws.cnt[cur ^ 1] + b), 0u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // ---- local list: the raised flags of the own rank range, in rank order
+      int Um = 0;
+      {
+        int base = 0;
+        const int vec = R >> 2;
+        for (int w0 = 0; w0 < vec; w0 += kBidThreads) {
+          const int w = w0 + tid;
+          int4 f = make_int4(0, 0, 0, 0);
+          if (w < vec) {
+            f = reinterpret_cast<const int4 *>(flags + o + r0)[w];
+            if (f.x | f.y | f.z | f.w) reinterpret_cast<int4 *>(flags + o + r0)[w] = make_int4(0, 0, 0, 0);
+          }
+          const int cnt = (f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0);
+          int incl = cnt;
+          for (int d = 1; d < 64; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+          }
+          if (lane == 63) wsum[wave] = incl;
+          __syncthreads();
+          int pos = base + incl - cnt, total = 0;
+          for (int wv = 0; wv < kBidWaves; ++wv) {
+            if (wv < wave) pos += wsum[wv];
+            total += wsum[wv];
+          }
+          if (cnt > 0) {
+            const int r = r0 + 4 * w;
+            if (f.x) llist[pos++] = a.ws.perm1[o + r];
+            if (f.y) llist[pos++] = a.ws.perm1[o + r + 1];
+            if (f.z) llist[pos++] = a.ws.perm1[o + r + 2];
+            if (f.w) llist[pos++] = a.ws.perm1[o + r + 3];
+          }
+          base += total;
+          __syncthreads();
+        }
+        Um = base;
+      }
+      // ---- bid
+      {
+        c.geom = TieGeom{n, 1024 / ((U + block_cnt - 1) / block_cnt)};
+        const float price_floor = a.eps < 0.f ? a.eps * (float)it : 0.f;
+        c.a_max = filter_target(price_floor) + 9.5367431640625e-07f;
+        const int ngroups = (Um + 63) >> 6;
+        int S = 1;
+        while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
+        const int gpb = kBidWaves / S;
+        const int seg = wave & (S - 1), gslot = wave / S;
+        for (int q0 = 0; q0 < ngroups; q0 += gpb) {
+          bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
+          if (q0 + gpb < ngroups) __syncthreads();
+        }
+      }
+      if (!team_barrier(ts, &s_flag)) return;
+      // ---- GetMax (emd_cuda.cu:181-194) for the own bidders
+      for (int u = tid; u < Um; u += kBidThreads) {
+        const int j = llist[u];
+        const int tgt = bo.bid[o + j];
+        if (tgt < 0) continue;
+        const float bi = bo.bid_inc[o + j];
+        const float mi = bo.max_inc[o + tgt];
+        if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
+          atomicMax(&bo.win[o + tgt], j);
+      }
+      if (!team_barrier(ts, &s_flag)) return;
+      // ---- Assign (emd_cuda.cu:196-215) for the own bidders; raised flags are counted for the next U
+      {
+        for (int u0 = 0; u0 < Um; u0 += kBidThreads) {
+          const int u = u0 + tid;
+          int raised = 0;
+          if (u < Um) {
+            const int j = llist[u];
+            const int tgt = bo.bid[o + j];
+            if (tgt < 0) {
+              if (!last) {
+                flags[o + a.ws.rank1[o + j]] = 1;
+                raised = 1;
+              }
+            } else {
+              int w = bo.win[o + tgt];
+              if (w >= 0)
+                a.ws.max_idx[o + tgt] = w;
+              else
+                w = a.ws.max_idx[o + tgt];
+              if (last || w == j) {
+                const int inv = a.ws.assignment_inv[o + tgt];
+                if (!last && inv != -1) {
+                  a.assignment[o + inv] = -1;
+                  flags[o + a.ws.rank1[o + inv]] = 1;
+                  raised = 1;
+                }
+                a.ws.assignment_inv[o + tgt] = j;
+                a.assignment[o + j] = tgt;
+                const float np = price[o + tgt] + bo.bid_inc[o + j];
+                price[o + tgt] = np;
+                const int pos = a.ws.rank2[o + tgt];
+                reinterpret_cast<float *>(a.ws.t4s + o + pos)[3] = filter_target(np);
+                reinterpret_cast<float *>(a.ws.pk + o + pos)[0] = np;
+                bo.max_inc[o + tgt] = -1e9f;
+              } else {
+                flags[o + a.ws.rank1[o + j]] = 1;
+                raised = 1;
+              }
+            }
+          }
+          const int rc = __popcll(__ballot(raised != 0));
+          if (rc > 0 && lane == 0)
+            __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(a.ws.cnt[cur ^ 1] + b), (unsigned)rc,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (!team_barrier(ts, &s_flag)) return;
+    }
+    // ---- distances of the final assignment (emd_cuda.cu:218-226), own slice of the bidder indices
+    {
+#pragma clang fp contract(off)
+      for (int e = r0 + tid; e < r0 + R; e += kBidThreads) {
+        const int k = a.assignment[o + e];
+        float d = 0.f;
+        if (k >= 0) {
+          const float *p = a.xyz1 + (o + e) * 3, *q = a.xyz2 + (o + k) * 3;
+          const float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+          d = (dx * dx + dy * dy) + dz * dz;
+        }
+        a.dist[o + e] = d;
+      }
+    }
+    // a team that serves several clouds: the flags / lists of the next cloud are its own, nothing to wait for
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
     int n, const int *__restrict__ bid, const float *__restrict__ bid_inc,
     const float *__restrict__ max_inc, int *__restrict__ win, const int *__restrict__ list,
@@ -907,6 +1464,8 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
   }
 }
 
+constexpr size_t kCtlBytes = 4 * (32 + 32 * 1024);  // up to 1024 teams
+
 EmdWs carve(void *workspace, int b, int n) {
   char *p = static_cast<char *>(workspace);
   const size_t arr = sn::align_up((size_t)b * n * 4, 256);
@@ -937,6 +1496,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.flags = reinterpret_cast<int *>(p); p += arr;
   ws.hist1 = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
   ws.bbox1 = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
+  ws.ctl = p; p += kCtlBytes;
   return ws;
 }
 
@@ -946,7 +1506,7 @@ extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
   return 16 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
          2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
-         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256);
+         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
 }
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
@@ -970,9 +1530,42 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   SN_REQUIRE(cloud_sort_count(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, s) == 0,
              "sn_emd_forward: cannot size the sort kernel's LDS");
   cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist1, ws.perm1, total);
-  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
+  // SN_EMD_LAUNCHES=1 selects the launch-per-phase form (4 launches per iteration) for A/B measurements
+  static const bool per_phase = [] { const char *e = getenv("SN_EMD_LAUNCHES"); return e && e[0] == '1'; }();
+  static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
+  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws, per_phase ? 0 : 1);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
   emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
+  if (!per_phase) {
+    int dev = 0, cus = 0;
+    SN_HIP(hipGetDevice(&dev));
+    SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    SN_REQUIRE(cus >= 1 && cus <= 1024, "sn_emd_forward: unexpected compute-unit count %d", cus);
+    // one workgroup of 16 waves per CU (the register budget admits exactly one): the whole grid is resident
+    // on an idle device, and the ticket order keeps it live next to other launches (see the kernel's header)
+    AuctionArgs args;
+    args.B = b;
+    args.n = n;
+    args.iters = iters;
+    args.eps = eps;
+    args.xyz1 = xyz1;
+    args.xyz2 = xyz2;
+    args.assignment = assignment;
+    args.dist = dist;
+    args.ws = ws;
+    args.ctl = static_cast<AuctionCtl *>(ws.ctl);
+    args.stats = stats;
+    args.tg = team_geometry(b, cus);
+    SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
+    SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus, kBidThreads, 0, s>>>(args)));
+    if (check) {  // debugging aid: a barrier that timed out leaves garbage in dist / assignment
+      unsigned abort_word = 0;
+      SN_HIP(hipStreamSynchronize(s));
+      SN_HIP(hipMemcpy(&abort_word, &args.ctl->abort, 4, hipMemcpyDeviceToHost));
+      SN_REQUIRE(abort_word == 0, "sn_emd_forward: a team barrier of the persistent auction timed out");
+    }
+    return sn::launch_status("sn_emd_forward");
+  }
   const int g_env = kBlocksPerCloud;
   const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
   const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);

@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the persistent auction reports a timed-out team barrier instead of returning garbage (debug aid)
+os.environ.setdefault("SN_EMD_CHECK", "1")
 
 
 def pytest_configure(config):
