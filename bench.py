@@ -347,7 +347,7 @@ def main():
 
     def read_kernels():
         ks = {}
-        for kname in ("chamfer_fwd", "emd_bid", "expansion_fwd", "p2i_max_splat"):
+        for kname in ("chamfer_fwd", "emd_bid", "emd_auction", "expansion_fwd", "p2i_max_splat"):
             ms = ctypes.c_double(0.0)
             cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
             ks[kname] = {"launches": int(cnt), "total_ms": ms.value,
@@ -392,7 +392,7 @@ def main():
 
     roofline = None
     if not args.no_roofline:
-        bid = kernels["emd_bid"]
+        bid = kernels["emd_auction"] if kernels["emd_auction"]["launches"] else kernels["emd_bid"]
         if bid["launches"]:
             flops = FLOP_PER_PAIR["emd_bid"] * float(hp.stats[0].item())     # this rank
             achieved = flops / (bid["total_ms"] * 1e-3) / 1e12
@@ -412,7 +412,7 @@ def main():
                 "launches": bid["launches"], "avg_launch_us": bid["avg_us"],
                 "pairs_per_launch_avg": float(hp.stats[0].item()) / bid["launches"],
             }
-            iso = kernels_isolated.get("emd_bid")
+            iso = kernels_isolated.get("emd_auction") if kernels_isolated.get("emd_auction", {}).get("launches") else kernels_isolated.get("emd_bid")
             if iso and iso["launches"]:
                 ach = flops / (iso["total_ms"] * 1e-3) / 1e12
                 roofline["isolated"] = {

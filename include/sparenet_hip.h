@@ -83,12 +83,17 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
  *          (cuda/emd/emd_module.py:43-54): they live in `workspace` here.
  * Requirements as the reference: n % 1024 == 0, b <= 512 (emd_module.py:36-39).
  * dist[b,n] fp32, assignment[b,n] int32.
+ * All iterations run in ONE persistent launch (one workgroup per compute unit; teams of
+ * workgroups own a cloud and synchronise through bounded, placement-independent barriers).
+ * Environment: SN_EMD_CHECK=1 makes the call synchronise and fail if a barrier timed out.
  * stats (optional device pointer, may be NULL): 2 x int64, zeroed by the caller
  *   stats[0] += sum over iterations and batch of unassigned_count * n
  *               (effective pair evaluations); stats[1] += iterations that had
- *               at least one bidder (one atomic per cloud per iteration: per-wave
- *               counters on one address measurably serialise the bid kernel). */
+ *               at least one bidder (one atomic per cloud per iteration).
+ * With SN_EMD_DIAG=1|2 in the environment the call also leaves phase timers of the first team
+ * in the workspace, 16 + 64*64 int64 words at sn_emd_diag_offset (tools/emd_ab.py). */
 size_t sn_emd_workspace_bytes(int b, int n);
+size_t sn_emd_diag_offset(int b, int n);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,
                    void *workspace, size_t workspace_bytes,

@@ -33,7 +33,7 @@ def lib():
         _lib.sn_prof_read.restype = ctypes.c_longlong
         _lib.sn_prof_enable.restype = None
         _lib.sn_prof_reset.restype = None
-        for name in ("sn_emd_workspace_bytes", "sn_p2i_max_workspace_bytes",
+        for name in ("sn_emd_workspace_bytes", "sn_emd_diag_offset", "sn_p2i_max_workspace_bytes",
                      "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes", "sn_mds_workspace_bytes", "sn_p2i_max_backward_workspace_bytes",
                      "sn_p2i_max_multi_workspace_bytes",
                      "sn_p2i_max_backward_multi_workspace_bytes", "sn_chamfer_workspace_bytes",

@@ -16,19 +16,19 @@
 //   assignment exactly as :196-215.
 //
 // MI355X design (measured history in DESIGN.md section 5)
-//   * 4 launches per iteration instead of 7: the unassigned list for the next iteration is
-//     produced by Assign itself (losers and evicted points append with a wave-aggregated
-//     atomic) -- no count / scan / compaction kernels.
-//   * Bid is the hot kernel.  The pairwise search is a filtered one: a [targets x 4].[4 x bidders]
+//   * ONE launch per call for all iterations (the reference: 7 launches per iteration): a persistent
+//     kernel in which a team of workgroups owns a cloud and walks compact -> bid -> GetMax -> Assign with
+//     team barriers in between (emd_auction_kernel below).
+//   * Bid is the hot phase.  The pairwise search is a filtered one: a [targets x 4].[4 x bidders]
 //     fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32) gives |t|^2 - 2 t.x for 256 pairs per
 //     instruction and a per-lane threshold decides which pairs can still enter a bidder's
 //     top-2; the rare survivors are queued in LDS and evaluated 64 at a time with the
 //     reference's exact arithmetic (correctly rounded sqrt, fp64 detour).  Thresholds are seeded
 //     from the bidder's previous two favourites (first iteration: two near targets found
-//     through a Morton sort of the targets).  Results stay bit-identical.
-//   * the unassigned count is only known on the device, so a fixed XCD-aware grid adapts:
-//     S = 2^k <= 64 waves share one group of 64 bidders, each scanning n/S targets; up to
-//     16 of them merge in LDS, the rest through emd_bid_finish_kernel.
+//     through a Hilbert sort of the targets).  Results stay bit-identical.
+//   * bidders are served in Hilbert order, 64 neighbours per group, S = 2^k <= 16 waves of a workgroup
+//     sharing a group (each takes the superblocks sb with sb mod S == its segment); superblocks and
+//     16-target blocks outside the reach of the group's filters are skipped by bounding box.
 //   * GetMax: deterministic atomicMax of the bidder index inside the window.
 #include <cstdlib>
 
@@ -37,20 +37,8 @@
 
 namespace {
 
-// split constants (tools build A/B variants with -D)
-#ifndef SN_EMD_G
-#define SN_EMD_G 32
-#endif
 constexpr int kThreads = 256;     // element-wise kernels
-constexpr int kBlocksPerCloud = SN_EMD_G;  // bid kernel: 32 workgroups x 16 waves = 512 waves per cloud (swept 8..64)
 
-// Optional per-wave phase stamps of the bid kernel (make diag; tools/emd_timeline.py): the 100 MHz
-// wall clock at the phase boundaries and a few counters, 14 int64 per wave after the 8 stats words.
-#ifdef SN_EMD_DIAG
-#define DIAG(...) __VA_ARGS__
-#else
-#define DIAG(...)
-#endif
 
 struct Top2 {
   float best, better;
@@ -203,7 +191,7 @@ struct EmdWs {
 };
 
 __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
-                                int *__restrict__ assignment, EmdWs ws, int flag_init) {
+                                int *__restrict__ assignment, EmdWs ws) {
 #pragma clang fp contract(off)
   const long total = (long)B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -217,7 +205,7 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.bid2[e] = -1;
     ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
     ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
-    ws.flags[e] = flag_init;  // persistent auction: every bidder starts flagged (= unassigned)
+    ws.flags[e] = 1;  // every bidder starts flagged (= unassigned)
     {  // stream position p of this cloud holds target k = tperm[p]
       const long bb = e / n;
       const int p = (int)(e - bb * n);
@@ -342,15 +330,6 @@ struct BidOut {
 constexpr int kBidWaves = 16;
 constexpr int kBidThreads = kBidWaves * 64;
 
-// S = 2^k <= 16 waves of one workgroup share a group of 64 bidders (superblock sb belongs to wave
-// sb mod S); chosen on the device from the unassigned count so that the fixed grid of G
-// workgroups per cloud stays busy when few bidders are left.
-__host__ __device__ inline int bid_split(int ngroups, int G) {
-  int s = 1;
-  while (s < kBidWaves && s * 2 * ngroups <= G * kBidWaves) s *= 2;
-  return s;
-}
-
 __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const Top2 &top,
                                          float eps) {
   if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
@@ -368,7 +347,7 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const
 }
 
 // ---------------------------------------------------------------------------------------
-// Bid kernel: a two-level filter in front of the exact evaluation.
+// Bid phase: a two-level filter in front of the exact evaluation.
 //
 // level 1 (matrix cores).  A wave serves 64 bidders and walks its target segment in
 //   superblocks of 64 targets.  For bidder group g (16 bidders) and target block q (16 targets)
@@ -438,336 +417,12 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
   return __builtin_fmaf(r * __builtin_fabsf(r), 1.00000095367431640625f, base);
 }
 
-__global__ __launch_bounds__(kBidThreads, 4) void emd_bid_kernel(
-    int B, int G, int n, float eps, float price_floor, const float *__restrict__ xyz1,
-    const f4 *__restrict__ t4s, const float2 *__restrict__ pk, const int *__restrict__ rank2,
-    const f4 *__restrict__ mstream,
-    const float *__restrict__ bbox, const float *__restrict__ sbbox, const int *__restrict__ list, const int *__restrict__ cnt, BidOut A,
-    long long *__restrict__ stats) {
-  __shared__ WaveTab tabs[kBidWaves];
-  __shared__ GroupAcc gacc[kBidWaves];
-  if (threadIdx.x < kBidWaves) {
-    gacc[threadIdx.x].lock = 0;
-    gacc[threadIdx.x].arrived = 0;
-  }
-  __syncthreads();
-  // XCD-aware decode of the 1-D grid: workgroup `lin` runs on XCD lin % 8 and every cloud's
-  // workgroups share that residue, so a cloud's streams + prices stay in ONE 4 MB L2
-  // (4 clouds per XCD at B = 32) instead of cycling through every L2.
-  const int lin = blockIdx.x;
-  const int xcd = lin & 7, rr = lin >> 3;
-  const int b = (rr / G) * 8 + xcd;
-  const int bx = rr % G;  // this workgroup's index among its cloud's G workgroups
-  if (b >= B) return;
-  const int U = cnt[b];
-  if (U == 0) return;
-  if (stats && bx == 0 && threadIdx.x == 0) {
-    atomicAdd(reinterpret_cast<unsigned long long *>(stats), (unsigned long long)U * n);
-    if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(stats) + 1, 1ULL);
-  }
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // provably uniform
-  const int lane = threadIdx.x & 63;
-  const int row = lane >> 4, col = lane & 15;
-  const size_t o = (size_t)b * n;
-  const float *__restrict__ p1 = xyz1 + o * 3;
-  const f4 *__restrict__ t4 = t4s + o;
-  const float2 *__restrict__ pkc = pk + o;
-  const int *__restrict__ rk2 = rank2 + o;
-  const int *__restrict__ lst = list + o;
-  WaveTab &T = tabs[wave];
-
-  const int ngroups = (U + 63) >> 6;
-  const int S = bid_split(ngroups, G);  // waves per bidder group
-  const int gpb = kBidWaves / S;        // bidder groups per workgroup
-  const int seg = wave & (S - 1);       // this wave takes superblocks sb with sb mod S == seg
-  const int gslot = wave / S;
-  const int nsb = n >> 6;
-
-  // reference partition, only needed to order exact ties (emd_cuda.cu:108-109,136)
-  const int block_cnt = n / 1024;
-  const TieGeom geom = {n, 1024 / ((U + block_cnt - 1) / block_cnt)};
-  // upper bound of every A'_k (+ 4 ulp of 3: filter_target is only monotone up to rounding)
-  const float a_max = filter_target(price_floor) + 9.5367431640625e-07f;
-  float tmax = 0.f;  // upper bound of every stored |t|^2: the far corner of the bounding box
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const float lo = bbox[b * 6 + a], hi = bbox[b * 6 + 3 + a];
-    tmax += __builtin_fmaxf(lo * lo, hi * hi);
-  }
-  tmax *= 1.0001f;
-
-  // a workgroup takes gpb consecutive bidder groups per pass
-  for (int q0 = bx * gpb; q0 < ngroups; q0 += G * gpb) {  // uniform per block
-    const int grp = q0 + gslot;
-    const int u = grp * 64 + lane;
-    const bool active = grp < ngroups && u < U;
-    DIAG(const long long dg_t0 = __builtin_amdgcn_s_memrealtime(); long long dg_t1 = dg_t0, dg_t2 = dg_t0;
-         long long dg_hit = 0, dg_batch = 0, dg_worth = 0;
-         int dg_vis = 0, dg_nb = 0, dg_hb = 0, dg_mf = 0, dg_q = 0, dg_p2 = 0;)
-    const int j = lst[active ? u : 0];
-    Top2 top = {-1e9f, -1e9f, -1, -1};
-
-    if (grp < ngroups) {  // wave-uniform
-      // wave-uniform bounding boxes of the wave's four subgroups of 16 bidders (lanes 16 g ..
-      // 16 g + 15 = the bidders MFMA group g filters for)
-      float blo[4][3], bhi[4][3];
-      float own_slack2;      // 2 x the filter slack of this lane's own bidder
-      {
-        const float x1 = p1[j * 3 + 0], y1 = p1[j * 3 + 1], z1 = p1[j * 3 + 2];
-        {
-#pragma clang fp contract(off)
-          const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
-          own_slack2 = 2.f * 3.814697265625e-06f * (tmax + xx);
-          const float v[3] = {x1, y1, z1};
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            const float lo = row16_min(active ? v[a] : 3.0e38f), hi = row16_max(active ? v[a] : -3.0e38f);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {  // wave-uniform: they live in SGPRs
-              blo[g][a] = lane_value(lo, 16 * g);
-              bhi[g][a] = lane_value(hi, 16 * g);
-            }
-          }
-        }
-        // seed the filter with the bidder's previous two favourites under today's prices:
-        // both are real targets, so the final `better` is at least the smaller of the two.
-        float cm = -1e9f;
-        const int pa = A.bid[o + j], pb = A.bid2[o + j];
-        if (pa >= 0 && pb >= 0) {
-          const int qa = rk2[pa], qb = rk2[pb];
-          const f4 ta = t4[qa], tb = t4[qb];
-          const float da = bid_value(ta.x, ta.y, ta.z, pkc[qa].x, x1, y1, z1);
-          const float db = bid_value(tb.x, tb.y, tb.z, pkc[qb].x, x1, y1, z1);
-          cm = __builtin_fminf(da, db);
-        }
-        T.x[lane] = x1;
-        T.y[lane] = y1;
-        T.z[lane] = z1;
-        T.cm[lane] = active ? cm : 3.0e38f;  // no bidder: a threshold of -inf, never a hit
-        T.best[lane] = -1e9f;
-        T.better[lane] = -1e9f;
-        T.bi[lane] = -1;
-        T.bi2[lane] = -1;
-      }
-      // the four bidders this lane filters for: bidder 16 g + col of the wave's group
-      float thr[4], base[4], bop[4];  // T', slack - |x|^2, MFMA B operand
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma clang fp contract(off)
-        const int c = 16 * g + col;
-        const float x = T.x[c], y = T.y[c], z = T.z[c];
-        const float xx = (x * x + y * y) + z * z;
-        base[g] = 3.814697265625e-06f * (tmax + xx) - xx;
-        thr[g] = coarse_threshold(T.cm[c], base[g], a_max);
-        bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
-      }
-      int qcount = 0;  // wave-uniform
-      DIAG(dg_t1 = __builtin_amdgcn_s_memrealtime();)
-
-      // 64 (or the last `count`) queued pairs, one per lane
-      auto batch = [&](int first, int count) {
-        DIAG(const long long dg_b0 = __builtin_amdgcn_s_memrealtime(); ++dg_nb;)
-        const bool on = lane < count;
-        const unsigned e = T.queue[first + (on ? lane : 0)];
-        const int c = (int)(e >> 20);
-        const f4 t = t4[e & 0xfffffu];       // both records are addressed by the stream position:
-        const float2 pq = pkc[e & 0xfffffu];  // one round trip for coordinates, A', price, index
-        const int k = __float_as_int(pq.y);
-        const float sq = sq_dist(t.x, t.y, t.z, T.x[c], T.y[c], T.z[c]);
-        bool pend = on && filter_pass(sq, t.w, filter_thr(T.cm[c]));  // level 2
-        DIAG(dg_q += count; dg_p2 += __popcll(__ballot(pend));)
-        float d = 0.f;
-        if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pq.x);
-        volatile int *own = T.owner;
-        while (__any(pend)) {  // lanes holding pairs of the same bidder take turns
-          asm volatile("" ::: "memory");
-          if (pend) own[c] = lane;
-          if (pend && own[c] == lane) {
-            Top2 tp = {T.best[c], T.better[c], T.bi[c], T.bi2[c]};
-            top2_push(tp, d, k, geom);
-            T.best[c] = tp.best;
-            T.better[c] = tp.better;
-            T.bi[c] = tp.best_i;
-            T.bi2[c] = tp.better_i;
-            T.cm[c] = __builtin_fmaxf(T.cm[c], tp.better);
-            pend = false;
-          }
-        }
-        asm volatile("" ::: "memory");
-        DIAG(dg_batch += __builtin_amdgcn_s_memrealtime() - dg_b0;)
-      };
-
-      // Superblock pruning.  A pair passes the coarse filter only if |t - x_j|^2 (up to the slack)
-      // is below T'_j + |x_j|^2; r2max is the largest such reach over the wave's bidders, and a
-      // superblock whose bounding box is farther than that from the bidders' box cannot produce a
-      // single hit -- skipping it changes nothing.  64 superblocks are tested at a time, lane =
-      // superblock; the reach shrinks as the thresholds tighten.
-      float r2g[4];  // per subgroup
-      auto refresh_reach = [&]() {
-        const float v = row16_max(active ? coarse_threshold(T.cm[lane], own_slack2, a_max) : -3.0e38f);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float r = lane_value(v, 16 * g);
-          r2g[g] = r > 0.f ? r * 1.0001f : r;
-        }
-      };
-      refresh_reach();
-      const f4 *ms = mstream + (size_t)b * nsb * 64 + lane;
-      const float *sbb = sbbox + (size_t)b * nsb * 32;
-      // bit g: the block of 16 targets whose box is (lo4, hi4) can hold a hit for a bidder of subgroup g.
-      // The box stays in the lane's registers for the whole pass: the re-evaluation after every drain used
-      // to load it again (two dependent-free but cold global reads, ~1 us each time).
-      auto worth = [&](const f4 lo4, const f4 hi4) {
-        unsigned m = 0;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float gx = __builtin_fmaxf(__builtin_fmaxf(lo4.x - bhi[g][0], blo[g][0] - lo4.w), 0.f);
-          const float gy = __builtin_fmaxf(__builtin_fmaxf(lo4.y - bhi[g][1], blo[g][1] - hi4.x), 0.f);
-          const float gz = __builtin_fmaxf(__builtin_fmaxf(lo4.z - bhi[g][2], blo[g][2] - hi4.y), 0.f);
-          m |= (((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2g[g] ? 1u : 0u) << g;
-        }
-        return m;
-      };
-      // the nibbles of a quad of lanes side by side: bit 4 q + g of superblock (lane >> 2)
-      auto quad_mask = [&](unsigned m) {
-        const unsigned m0 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x00, 0xf, 0xf, true);  // quad_perm 0,0,0,0
-        const unsigned m1 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x55, 0xf, 0xf, true);  // 1,1,1,1
-        const unsigned m2 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xAA, 0xf, 0xf, true);  // 2,2,2,2
-        const unsigned m3 = (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xFF, 0xf, 0xf, true);  // 3,3,3,3
-        return m0 | (m1 << 4) | (m2 << 8) | (m3 << 12);
-      };
-      // Lane 4 i + q tests block q of the wave's i-th own superblock (superblock i S + seg): 16 own
-      // superblocks per pass.
-      const int owned4 = (nsb / S) * 4;
-      for (int t0 = 0; t0 < owned4; t0 += 64) {
-        const int task = t0 + lane;
-        const int sbl = (task >> 2) * S + seg;
-        const bool mine = task < owned4;
-        DIAG(const long long dg_w0 = __builtin_amdgcn_s_memrealtime();)
-        f4 box_lo = {0.f, 0.f, 0.f, 0.f}, box_hi = {0.f, 0.f, 0.f, 0.f};
-        if (mine) {
-          box_lo = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8);
-          box_hi = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8 + 4);
-        }
-        unsigned gmask = quad_mask(mine ? worth(box_lo, box_hi) : 0u);
-        unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
-        DIAG(dg_worth += __builtin_amdgcn_s_memrealtime() - dg_w0;)
-        f4 a_next = {0.f, 0.f, 0.f, 0.f};
-        int next_sb = -1;  // superblock whose operand is already in flight
-        while (todo) {
-          const int tl = __builtin_ctzll(todo);
-          const int sb = ((t0 + tl) >> 2) * S + seg;
-          todo &= todo - 1;
-          const int kb = sb * 64;
-          const f4 a = sb == next_sb ? a_next : ms[(size_t)sb * 64];
-          if (todo) {
-            next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
-            a_next = ms[(size_t)next_sb * 64];
-          }
-          bool drained = false;
-          const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, tl);
-          DIAG(++dg_vis; dg_mf += __builtin_popcount(gm);)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            if (!(gm & (0x1111u << g))) continue;  // wave-uniform: nothing for this subgroup here
-            const f4 zero = {0.f, 0.f, 0.f, 0.f};
-            const f4 far = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-            // only the (block, subgroup) pairs whose boxes are within reach go through the matrix cores
-            const f4 d0 = (gm >> g) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0) : far;
-            const f4 d1 = (gm >> (4 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0) : far;
-            const f4 d2 = (gm >> (8 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0) : far;
-            const f4 d3 = (gm >> (12 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0) : far;
-            if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
-              DIAG(const long long dg_h0 = __builtin_amdgcn_s_memrealtime(); ++dg_hb;)
-              // bit 4 q + r  <->  stream position kb + 16 q + 4 row + r
-              unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
-                            hits4(d3, thr[g], 12);
-              while (__any(hm != 0)) {
-                const bool has = hm != 0;
-                const int i = has ? __builtin_ctz(hm) : 0;
-                hm &= hm - 1;
-                const unsigned long long bal = __ballot(has);
-                const int pos = qcount + (int)__builtin_amdgcn_mbcnt_hi(
-                                             (unsigned)(bal >> 32),
-                                             __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (has)
-                  T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
-                                 ((unsigned)(16 * g + col) << 20);
-                qcount += __popcll(bal);
-                while (qcount >= 64) {
-                  qcount -= 64;
-                  batch(qcount, 64);
-                  drained = true;
-                }
-              }
-              DIAG(dg_hit += __builtin_amdgcn_s_memrealtime() - dg_h0;)
-            }
-          }
-          if (drained) {  // tighter thresholds: less reach, fewer blocks left to visit
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg)
-              thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
-            refresh_reach();
-            if (todo) {
-              const bool left = (todo >> (lane & ~3)) & 1ull;
-              gmask = quad_mask(left ? worth(box_lo, box_hi) : 0u);
-              todo = __ballot(gmask != 0u && (lane & 3) == 0);
-            }
-          }
-        }
-      }
-      if (qcount > 0) batch(0, qcount);
-      top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
-      DIAG(dg_t2 = __builtin_amdgcn_s_memrealtime();)
-    }
-    // Merge the S partial results of a bidder group in ARRIVAL order, without a barrier: a wave
-    // that is done takes the group's lock, folds its partial into the group accumulator (the
-    // first arrival just stores it) and leaves; the last arrival holds the complete top-2 and
-    // emits.  Early waves free their SIMD slots instead of waiting for the slowest segment.
-    bool emit = seg == 0;  // S == 1: every wave owns its group
-    if (S > 1 && grp < ngroups) {
-      GroupAcc &ga = gacc[gslot];
-      if (lane == 0)
-        while (atomicCAS(&ga.lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-      const int arrived = ga.arrived;
-      if (arrived > 0)
-        top2_merge(top, ga.best[lane], ga.better[lane], ga.bi[lane], ga.bi2[lane], geom);
-      emit = arrived == S - 1;
-      if (!emit) {
-        ga.best[lane] = top.best;
-        ga.better[lane] = top.better;
-        ga.bi[lane] = top.best_i;
-        ga.bi2[lane] = top.better_i;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      if (lane == 0) {
-        ga.arrived = emit ? 0 : arrived + 1;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        atomicExch(&ga.lock, 0);
-      }
-    }
-    if (emit && active) emit_bid(A, o, j, top, eps);
-    DIAG(if (stats && lane == 0 && q0 == bx * gpb && grp < ngroups) {
-      const long long dg_t3 = __builtin_amdgcn_s_memrealtime();
-      long long *r = stats + 8 + ((size_t)(blockIdx.x % 1024) * 16 + wave) * 14;
-      r[0] = dg_t3; r[1] = dg_t1 - dg_t0; r[2] = dg_t2 - dg_t1; r[3] = dg_t3 - dg_t2; r[4] = dg_vis; r[5] = dg_nb;
-      r[6] = dg_hb; r[7] = dg_hit; r[8] = dg_batch; r[9] = dg_worth; r[10] = dg_mf; r[11] = dg_t0;
-      r[12] = dg_q; r[13] = dg_p2;
-    })
-    // the accumulators and tables are reused by the block's next work item
-    if (q0 + G * gpb < ngroups) __syncthreads();
-  }
-}
-
-
 // =======================================================================================
 // Persistent auction: ALL iterations of a call in ONE launch.
 //
-// The launch-per-phase form above pays, per iteration, four kernel boundaries, four grids that start with
-// cold L1/L2 and three small kernels of 5-13 us each: in the 40 late iterations (a few hundred bidders per
-// cloud) that is two thirds of the time.  Here a TEAM of G workgroups owns a cloud for the whole call and
-// walks  compact -> bid -> [barrier] -> getmax -> [barrier] -> assign -> [barrier]  with a team barrier
+// A launch-per-phase form (bid / GetMax / Assign / compact kernels, 200 launches per call; round 1) pays
+// four kernel boundaries and four cold grids per iteration.  Here a TEAM of G workgroups owns a cloud for
+// the whole call and walks  compact -> bid -> [barrier] -> getmax -> [barrier] -> assign -> [barrier]  with a team barrier
 // (monotonic counter, agent-scope release / acquire: placement independent) between the phases.
 //   * Workgroup m of a team owns the Morton RANKS [m n/G, (m+1) n/G) of the bidders for the whole call:
 //     it compacts its own raised flags into a local list (no global scan), bids for those bidders, runs
@@ -870,8 +525,7 @@ struct BidCtx {
   BidOut A;
 };
 
-// One group of 64 bidders, seen by one of its S segment-waves: the body of emd_bid_kernel's work item
-// (same filters, same queue, same exact path) with the bidder list given as a pointer.
+// One group of 64 bidders, seen by one of its S segment-waves.
 __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc &ga, const int *lst,
                                           int count, int grp, int ngroups, int S, int seg, int lane) {
   const int row = lane >> 4, col = lane & 15;
@@ -1103,6 +757,11 @@ struct AuctionArgs {
   AuctionCtl *ctl;
   long long *stats;
   TeamGeom tg;
+  int diag;  // SN_EMD_DIAG (tools/emd_ab.py): dwords[4..11] += 100 MHz ticks of team 0 / workgroup 0 per phase
+             // (compact, -, bid, barrier, getmax, barrier, assign, barrier); 2: also per iteration and
+             // workgroup at dwords[16 + ((it * 8 + m) * 8 + phase)].  dwords = the diag area of the workspace
+             // (sn_emd_diag_offset), zeroed by the call.
+  long long *dwords;
 };
 
 __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs a) {
@@ -1184,6 +843,16 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
         __hip_atomic_store(reinterpret_cast<unsigned *>(a.ws.cnt[cur ^ 1] + b), 0u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       }
+      const bool dg = a.diag && team == 0 && tid == 0;
+      long long tk = dg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+      auto tick = [&](int slot) {
+        if (dg) {
+          const long long now = (long long)__builtin_amdgcn_s_memrealtime();
+          if (m == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + slot, (unsigned long long)(now - tk));
+          if (a.diag >= 2 && m < 8 && it < 64) a.dwords[16 + ((it * 8 + m) * 8 + (slot - 4))] = now - tk;
+          tk = now;
+        }
+      };
       // ---- local list: the raised flags of the own rank range, in rank order
       int Um = 0;
       {
@@ -1221,6 +890,8 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
         }
         Um = base;
       }
+      tick(4);
+      tick(5);
       // ---- bid
       {
         c.geom = TieGeom{n, 1024 / ((U + block_cnt - 1) / block_cnt)};
@@ -1236,7 +907,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
           if (q0 + gpb < ngroups) __syncthreads();
         }
       }
+      if (a.diag) __syncthreads();
+      tick(6);
       if (!team_barrier(ts, &s_flag)) return;
+      tick(7);
       // ---- GetMax (emd_cuda.cu:181-194) for the own bidders
       for (int u = tid; u < Um; u += kBidThreads) {
         const int j = llist[u];
@@ -1247,7 +921,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
         if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
           atomicMax(&bo.win[o + tgt], j);
       }
+      if (a.diag) __syncthreads();
+      tick(8);
       if (!team_barrier(ts, &s_flag)) return;
+      tick(9);
       // ---- Assign (emd_cuda.cu:196-215) for the own bidders; raised flags are counted for the next U
       {
         for (int u0 = 0; u0 < Um; u0 += kBidThreads) {
@@ -1294,7 +971,10 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+      if (a.diag) __syncthreads();
+      tick(10);
       if (!team_barrier(ts, &s_flag)) return;
+      tick(11);
     }
     // ---- distances of the final assignment (emd_cuda.cu:218-226), own slice of the bidder indices
     {
@@ -1311,135 +991,6 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
       }
     }
     // a team that serves several clouds: the flags / lists of the next cloud are its own, nothing to wait for
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void emd_getmax_kernel(
-    int n, const int *__restrict__ bid, const float *__restrict__ bid_inc,
-    const float *__restrict__ max_inc, int *__restrict__ win, const int *__restrict__ list,
-    const int *__restrict__ cnt) {
-  const int b = blockIdx.y;
-  const int U = cnt[b];
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
-    const int j = list[(size_t)b * n + u];
-    const int tgt = bid[(size_t)b * n + j];
-    if (tgt < 0) continue;  // no bid (non-finite input)
-    const float bi = bid_inc[(size_t)b * n + j];
-    const float mi = max_inc[(size_t)b * n + tgt];
-    if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
-      atomicMax(&win[(size_t)b * n + tgt], j);
-  }
-}
-
-__global__ __launch_bounds__(kThreads) void emd_assign_kernel(
-    int n, int *__restrict__ assignment, int *__restrict__ assignment_inv,
-    float *__restrict__ price, const int *__restrict__ bid, const float *__restrict__ bid_inc,
-    float *__restrict__ max_inc, int *__restrict__ max_idx, const int *__restrict__ win,
-    const int *__restrict__ list, const int *__restrict__ cnt, const int *__restrict__ rank1,
-    int *__restrict__ flags,
-    const int *__restrict__ rank2, f4 *__restrict__ t4s, float2 *__restrict__ pk, int last) {
-  const int b = blockIdx.y;
-  const int U = cnt[b];
-  const size_t o = (size_t)b * n;
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < U; u += gridDim.x * blockDim.x) {
-    const int j = list[o + u];
-    const int tgt = bid[o + j];
-    if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
-      if (!last) flags[o + rank1[o + j]] = 1;
-      continue;
-    }
-    // GetMax only writes max_idx when some bidder's increment is within 1e-6 of max_increments, and the
-    // reference never clears that tensor (emd_cuda.cu:181-194, emd_module.py:50: zeros): when nobody is in
-    // the window -- max_increments still holds its initial 0 and every increment is negative, i.e. eps < 0 --
-    // Assign compares against the entry of an EARLIER iteration (initially 0).  Every bidder of a target
-    // sees the same `win`, so they all take the same branch: no read races a write.
-    int w = win[o + tgt];
-    if (w >= 0)
-      max_idx[o + tgt] = w;
-    else
-      w = max_idx[o + tgt];
-    if (last || w == j) {
-      const int inv = assignment_inv[o + tgt];
-      if (!last && inv != -1) {
-        assignment[o + inv] = -1;
-        flags[o + rank1[o + inv]] = 1;  // evicted: bids again
-      }
-      assignment_inv[o + tgt] = j;
-      assignment[o + j] = tgt;
-      const float np = price[o + tgt] + bid_inc[o + j];
-      price[o + tgt] = np;
-      const int pos = rank2[o + tgt];  // keep the bid kernel's records in sync
-      reinterpret_cast<float *>(t4s + o + pos)[3] = filter_target(np);
-      reinterpret_cast<float *>(pk + o + pos)[0] = np;
-      max_inc[o + tgt] = -1e9f;
-    } else {
-      flags[o + rank1[o + j]] = 1;  // lost: bids again
-    }
-  }
-}
-
-// next unassigned list = the flagged bidders in Morton-rank order (one workgroup per cloud), so
-// that the 64 bidders of a wave stay spatial neighbours in every iteration
-__global__ __launch_bounds__(1024) void emd_compact_kernel(int n, const int *__restrict__ perm1,
-                                                           int *__restrict__ flags,
-                                                           int *__restrict__ list_next,
-                                                           int *__restrict__ cnt_next) {
-  __shared__ int wsum[16];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const size_t o = (size_t)b * n;
-  // rank r = 4 (1024 i + tid) + e: every pass reads one coalesced int4 per lane
-  const int vec = n / 4;                // int4 words per cloud (n is a multiple of 1024)
-  const int passes = (vec + 1023) / 1024;  // ceil: n = 5120, 6144, ... need the partial last pass
-  int base = 0;
-  for (int i = 0; i < passes; ++i) {
-    const int w = i * 1024 + tid;
-    int4 f = make_int4(0, 0, 0, 0);
-    if (w < vec) {
-      f = reinterpret_cast<const int4 *>(flags + o)[w];
-      if (f.x | f.y | f.z | f.w) reinterpret_cast<int4 *>(flags + o)[w] = make_int4(0, 0, 0, 0);
-    }
-    const int c = f.x + f.y + f.z + f.w;
-    int incl = c;
-    for (int m = 1; m < 64; m <<= 1) {
-      const int v = __shfl_up(incl, m);
-      if ((tid & 63) >= m) incl += v;
-    }
-    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
-    __syncthreads();
-    int pos = base + incl - c, total = 0;
-    for (int wv = 0; wv < 16; ++wv) {
-      if (wv < (tid >> 6)) pos += wsum[wv];
-      total += wsum[wv];
-    }
-    if (c > 0) {
-      const int r = 4 * w;
-      if (f.x) list_next[o + pos++] = perm1[o + r];
-      if (f.y) list_next[o + pos++] = perm1[o + r + 1];
-      if (f.z) list_next[o + pos++] = perm1[o + r + 2];
-      if (f.w) list_next[o + pos++] = perm1[o + r + 3];
-    }
-    base += total;
-    __syncthreads();
-  }
-  if (tid == 0) cnt_next[b] = base;
-}
-
-__global__ __launch_bounds__(kThreads) void emd_calcdist_kernel(
-    int B, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    const int *__restrict__ assignment, float *__restrict__ dist) {
-#pragma clang fp contract(off)
-  const long total = (long)B * n;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
-    const int k = assignment[e];
-    if (k < 0) {  // only with iters == 0 (undefined in the reference)
-      dist[e] = 0.f;
-      continue;
-    }
-    const long bb = e / n;
-    const float *a = xyz1 + e * 3, *o = xyz2 + (bb * n + k) * 3;
-    const float dx = a[0] - o[0], dy = a[1] - o[1], dz = a[2] - o[2];
-    dist[e] = (dx * dx + dy * dy) + dz * dz;
   }
 }
 
@@ -1464,7 +1015,9 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
   }
 }
 
-constexpr size_t kCtlBytes = 4 * (32 + 32 * 1024);  // up to 1024 teams
+constexpr size_t kDiagWords = 16 + 64 * 64;                        // int64 phase timers (SN_EMD_DIAG)
+constexpr size_t kCtlWords = 32 + 32 * 1024;                        // ticket, abort, up to 1024 team counters
+constexpr size_t kCtlBytes = 4 * kCtlWords + 8 * kDiagWords;
 
 EmdWs carve(void *workspace, int b, int n) {
   char *p = static_cast<char *>(workspace);
@@ -1509,6 +1062,11 @@ extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
          2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
 }
 
+// byte offset of the diagnostic words (SN_EMD_DIAG) inside the workspace
+extern "C" size_t sn_emd_diag_offset(int b, int n) {
+  return sn_emd_workspace_bytes(b, n) - 8 * kDiagWords;
+}
+
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
                               int iters, float *dist, int *assignment, void *workspace,
                               size_t workspace_bytes, long long *stats, void *stream) {
@@ -1530,13 +1088,11 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   SN_REQUIRE(cloud_sort_count(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, s) == 0,
              "sn_emd_forward: cannot size the sort kernel's LDS");
   cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist1, ws.perm1, total);
-  // SN_EMD_LAUNCHES=1 selects the launch-per-phase form (4 launches per iteration) for A/B measurements
-  static const bool per_phase = [] { const char *e = getenv("SN_EMD_LAUNCHES"); return e && e[0] == '1'; }();
   static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
-  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws, per_phase ? 0 : 1);
+  emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
   emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
-  if (!per_phase) {
+  {
     int dev = 0, cus = 0;
     SN_HIP(hipGetDevice(&dev));
     SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -1556,6 +1112,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     args.ctl = static_cast<AuctionCtl *>(ws.ctl);
     args.stats = stats;
     args.tg = team_geometry(b, cus);
+    static const int diag = [] { const char *e = getenv("SN_EMD_DIAG"); return e ? atoi(e) : 0; }();
+    args.diag = diag;
+    args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
+    if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
     SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus, kBidThreads, 0, s>>>(args)));
     if (check) {  // debugging aid: a barrier that timed out leaves garbage in dist / assignment
@@ -1566,28 +1126,6 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     }
     return sn::launch_status("sn_emd_forward");
   }
-  const int g_env = kBlocksPerCloud;
-  const int bid_grid = g_env * 8 * sn::ceil_div(b, 8);
-  const dim3 lin_grid(sn::ceil_div(n, kThreads * 4) < 16 ? sn::ceil_div(n, kThreads * 4) : 16, b);
-  for (int it = 0; it < iters; ++it) {
-    const int c = it & 1;
-    const BidOut bo = {ws.bid, ws.bid2, ws.bid_inc, ws.max_inc, ws.win};
-    // prices move by bid increments >= eps per iteration: a lower bound for every price
-    const float price_floor = eps < 0.f ? eps * (float)it : 0.f;
-    SN_TIMED("emd_bid", s, (emd_bid_kernel<<<bid_grid, kBidThreads, 0, s>>>(
-        b, g_env, n, eps, price_floor, xyz1, ws.t4s, ws.pk, ws.rank2, ws.mstream, ws.bbox, ws.sbbox,
-        ws.list[c], ws.cnt[c], bo, stats)));
-    emd_getmax_kernel<<<lin_grid, kThreads, 0, s>>>(n, ws.bid, ws.bid_inc, ws.max_inc, ws.win,
-                                                    ws.list[c], ws.cnt[c]);
-    emd_assign_kernel<<<lin_grid, kThreads, 0, s>>>(n, assignment, ws.assignment_inv, ws.price,
-                                                    ws.bid, ws.bid_inc, ws.max_inc, ws.max_idx, ws.win,
-                                                    ws.list[c], ws.cnt[c], ws.rank1, ws.flags,
-                                                    ws.rank2, ws.t4s, ws.pk, it == iters - 1);
-    if (it + 1 < iters)
-      emd_compact_kernel<<<b, 1024, 0, s>>>(n, ws.perm1, ws.flags, ws.list[c ^ 1], ws.cnt[c ^ 1]);
-  }
-  emd_calcdist_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, assignment, dist);
-  return sn::launch_status("sn_emd_forward");
 }
 
 extern "C" int sn_emd_backward(const float *xyz1, const float *xyz2, const float *graddist,

@@ -1,17 +1,19 @@
 """EMD forward: wall time per call (HIP events) for a few batch sizes, and a parity check of the
-current path against the oracle.  SN_EMD_LAUNCHES=1 selects the launch-per-phase form."""
+current path against the oracle."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 import oracle
+import sparenet_amd._lib as _L
+if os.environ.get('AB_LIB'): _L.LIB_PATH = os.path.abspath(os.environ['AB_LIB'])
 from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
 
 dev = torch.device("cuda:0")
 N = 16384
 g = torch.Generator().manual_seed(1234)
 X = torch.rand(32, N, 3, generator=g); Y = torch.rand(32, N, 3, generator=g)
-mode = "per-phase launches" if os.environ.get("SN_EMD_LAUNCHES") == "1" else "persistent"
+mode = "persistent auction"
 if "--parity" in sys.argv:
     for b, iters in ((3, 50), (1, 7), (9, 3)):
         x, y = X[:b].numpy(), Y[:b].numpy()
@@ -20,9 +22,9 @@ if "--parity" in sys.argv:
         d, a = emd_forward_raw(X[:b].to(dev), Y[:b].to(dev), 0.005, iters, st)
         print(mode, "parity b", b, "iters", iters, bool(np.array_equal(a.cpu().numpy(), a0)),
               bool(np.array_equal(d.cpu().numpy(), d0)), int(st[0]) == aux["pairs_eff"], flush=True)
-for b in (32, 4, 1):
+for b in ((32,) if os.environ.get("AB_QUICK") else (32, 4, 1)):
     x, y = X[:b].to(dev), Y[:b].to(dev)
-    for iters in (1, 10, 50):
+    for iters in ((50,) if os.environ.get("AB_QUICK") else (1, 10, 50)):
         emd_forward_raw(x, y, 0.005, iters); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -30,3 +32,21 @@ for b in (32, 4, 1):
             emd_forward_raw(x, y, 0.005, iters)
         e1.record(); torch.cuda.synchronize()
         print(f"{mode}: B={b} iters={iters}: {e0.elapsed_time(e1)/5:.3f} ms per call", flush=True)
+
+if os.environ.get("SN_EMD_DIAG"):
+    for b in (32,):
+        x, y = X[:b].to(dev), Y[:b].to(dev)
+        _, _, ws = emd_forward_raw(x, y, 0.005, 50, return_workspace=True); torch.cuda.synchronize()
+        _L.lib().sn_emd_diag_offset.restype = __import__("ctypes").c_size_t
+        off = _L.lib().sn_emd_diag_offset(b, N)
+        v = ws[off:off + 8 * (16 + 64 * 64)].view(torch.int64).cpu().numpy()
+        names = ["compact", "-", "bid", "bar1", "getmax", "bar2", "assign", "bar3"]
+        print("team 0 / wg 0 phase time, us over the call:", {n_: round(float(v[4 + i]) / 100.0, 1) for i, n_ in enumerate(names)})
+        if os.environ.get("SN_EMD_DIAG") == "2":
+            t = v[16:16 + 50 * 64].reshape(50, 8, 8) / 100.0   # [it, wg, phase] us
+            print("per-iteration phase time in us, mean over the team's 8 workgroups / max:")
+            for it in (0, 1, 2, 3, 5, 8, 12, 20, 30, 40, 49):
+                print(f"  it {it:2d}:", " ".join(f"{names[p]} {t[it,:,p].mean():5.1f}/{t[it,:,p].max():5.1f}" for p in range(8)))
+            tail = t[10:]
+            print("  tail mean per iteration:", {names[p]: round(float(tail[:, :, p].mean()), 1) for p in range(8)},
+                  "sum", round(float(tail.mean(1).sum(1).mean()), 1))

@@ -16,5 +16,5 @@ for iters in (1, 50):
     for _ in range(3):
         emd_forward_raw(x, y, 0.005, iters)
     torch.cuda.synchronize(); lib.sn_prof_enable(0)
-    ms = ctypes.c_double(0); n = lib.sn_prof_read(b"emd_bid", ctypes.byref(ms))
-    print(f"iters={iters}: bid total {ms.value/3:.3f} ms per call over {n//3} launches")
+    ms = ctypes.c_double(0); n = lib.sn_prof_read(b"emd_auction", ctypes.byref(ms))
+    print(f"iters={iters}: auction kernel {ms.value/3:.3f} ms per call ({n//3} launch per call)")
