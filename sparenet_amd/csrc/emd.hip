@@ -38,6 +38,7 @@
 namespace {
 
 constexpr int kThreads = 256;     // element-wise kernels
+constexpr int kRankBins = 64;     // per cloud: counters of unassigned bidders per 1/64 of the Hilbert ranks
 
 
 struct Top2 {
@@ -172,7 +173,7 @@ struct EmdWs {
   int *max_idx;  // GetMax's winner per target; PERSISTS across iterations like the reference's tensor
   int *win;      // this iteration's in-window winner per target (-1: nobody was in the window)
   int *list[2];
-  int *cnt[2];
+  int *bins[2];  // [B, 64] ping-pong: flagged (= unassigned) bidders per 1/64 of the rank range
   f4 *t4s;       // [B, n] by stream position p: {x, y, z, A'} of target tperm[p]
   float2 *pk;    // [B, n] by stream position: {price, target index bits}
   int *rank2;    // [B, n] target index -> stream position
@@ -223,9 +224,9 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
       m[(2 * 16 + c) * 4 + q] = -2.f * z;
       m[(3 * 16 + c) * 4 + q] = tt;
     }
-    if (e < B) {
-      ws.cnt[0][e] = n;
-      ws.cnt[1][e] = 0;
+    if (e < (long)B * kRankBins) {
+      ws.bins[0][e] = n / kRankBins;  // every bidder starts unassigned
+      ws.bins[1][e] = 0;
     }
   }
 }
@@ -768,12 +769,13 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
   __shared__ WaveTab tabs[kBidWaves];
   __shared__ GroupAcc gacc[kBidWaves];
   __shared__ int wsum[kBidWaves];
-  __shared__ int s_flag, s_ticket;
+  __shared__ int s_flag, s_ticket, s_range[3], s_bins[kRankBins];
   const int tid = threadIdx.x;
   if (tid < kBidWaves) {
     gacc[tid].lock = 0;
     gacc[tid].arrived = 0;
   }
+  if (tid < kRankBins) s_bins[tid] = 0;
   if (tid == 0)
     s_ticket = (int)__hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
@@ -794,8 +796,8 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
   const int n = a.n, nsb = n >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
-  const int R = n / G;          // ranks owned by this workgroup (n % 1024 == 0, G <= 64: a multiple of 16)
-  const int r0 = m * R;
+  const int Rs = n / G, rs0 = m * Rs;  // static slice (final distances); n % 1024 == 0, G <= 64
+  const int binsize = n / kRankBins;   // ranks per counter bin (a multiple of 16)
   const int block_cnt = n / 1024;
   float *price = a.ws.price;
   int *flags = a.ws.flags;
@@ -804,7 +806,6 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
 
   for (int b = team; b < a.B; b += a.tg.teams) {
     const size_t o = (size_t)b * n;
-    int *llist = llist_all + o + r0;
     float tmax = 0.f;
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
@@ -828,21 +829,41 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
 
     for (int it = 0; it < a.iters; ++it) {
       const int cur = it & 1;
-      // unassigned bidders of the cloud: n in the first iteration, afterwards what Assign counted
-      const int U = it == 0 ? n
-                            : (int)__hip_atomic_load(reinterpret_cast<unsigned *>(a.ws.cnt[cur] + b),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (U == 0) break;  // every workgroup of the team reads the same value
-      const bool last = it == a.iters - 1;
-      if (m == 0 && tid == 0) {
-        if (a.stats) {
-          atomicAdd(reinterpret_cast<unsigned long long *>(a.stats), (unsigned long long)U * n);
-          if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
+      // The unassigned bidders per 1/64 of the rank range, counted by the previous Assign: every workgroup
+      // of the team derives the same split of the ranks into G contiguous, equally loaded ranges (bins are
+      // indivisible).  A static split left the team waiting ~20 us per late iteration for the workgroup
+      // whose region happened to hold two groups of bidders instead of one.
+      if (wave == 0) {
+        const int v = (int)__hip_atomic_load(reinterpret_cast<unsigned *>(a.ws.bins[cur] + b * kRankBins + lane),
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d);
+          if (lane >= d) incl += t;
         }
-        // the counter Assign fills in this iteration (read last at the top of the previous one)
-        __hip_atomic_store(reinterpret_cast<unsigned *>(a.ws.cnt[cur ^ 1] + b), 0u, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        const int total = __shfl(incl, 63);
+        int own = total > 0 ? (int)(((long long)(incl - v) * G) / total) : 0;
+        own = own < G - 1 ? own : G - 1;
+        const unsigned long long mine = __ballot(own == m);
+        if (lane == 0) {
+          s_range[0] = total;
+          s_range[1] = mine ? __builtin_ctzll(mine) * binsize : 0;
+          s_range[2] = __popcll(mine) * binsize;
+        }
       }
+      __syncthreads();
+      const int U = s_range[0], r0 = s_range[1], R = s_range[2];
+      if (U == 0) break;  // every workgroup of the team reads the same value
+      int *llist = llist_all + o + r0;
+      const bool last = it == a.iters - 1;
+      if (m == 0 && tid == 0 && a.stats) {
+        atomicAdd(reinterpret_cast<unsigned long long *>(a.stats), (unsigned long long)U * n);
+        if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
+      }
+      // the counters Assign fills in this iteration (read last at the top of the previous one)
+      if (m == 0 && wave == 1)
+        __hip_atomic_store(reinterpret_cast<unsigned *>(a.ws.bins[cur ^ 1] + b * kRankBins + lane), 0u,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool dg = a.diag && team == 0 && tid == 0;
       long long tk = dg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
       auto tick = [&](int slot) {
@@ -900,6 +921,9 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
         const int ngroups = (Um + 63) >> 6;
         int S = 1;
         while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
+#ifdef SN_EMD_SEQ_MAX
+        if (ngroups <= SN_EMD_SEQ_MAX) S = kBidWaves;  // A/B: few groups one after the other, 16 waves each
+#endif
         const int gpb = kBidWaves / S;
         const int seg = wave & (S - 1), gslot = wave / S;
         for (int q0 = 0; q0 < ngroups; q0 += gpb) {
@@ -927,48 +951,53 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
       tick(9);
       // ---- Assign (emd_cuda.cu:196-215) for the own bidders; raised flags are counted for the next U
       {
-        for (int u0 = 0; u0 < Um; u0 += kBidThreads) {
-          const int u = u0 + tid;
-          int raised = 0;
-          if (u < Um) {
-            const int j = llist[u];
-            const int tgt = bo.bid[o + j];
-            if (tgt < 0) {
-              if (!last) {
-                flags[o + a.ws.rank1[o + j]] = 1;
-                raised = 1;
-              }
-            } else {
-              int w = bo.win[o + tgt];
-              if (w >= 0)
-                a.ws.max_idx[o + tgt] = w;
-              else
-                w = a.ws.max_idx[o + tgt];
-              if (last || w == j) {
-                const int inv = a.ws.assignment_inv[o + tgt];
-                if (!last && inv != -1) {
-                  a.assignment[o + inv] = -1;
-                  flags[o + a.ws.rank1[o + inv]] = 1;
-                  raised = 1;
-                }
-                a.ws.assignment_inv[o + tgt] = j;
-                a.assignment[o + j] = tgt;
-                const float np = price[o + tgt] + bo.bid_inc[o + j];
-                price[o + tgt] = np;
-                const int pos = a.ws.rank2[o + tgt];
-                reinterpret_cast<float *>(a.ws.t4s + o + pos)[3] = filter_target(np);
-                reinterpret_cast<float *>(a.ws.pk + o + pos)[0] = np;
-                bo.max_inc[o + tgt] = -1e9f;
-              } else {
-                flags[o + a.ws.rank1[o + j]] = 1;
-                raised = 1;
-              }
-            }
+        unsigned *nextbins = reinterpret_cast<unsigned *>(a.ws.bins[cur ^ 1] + b * kRankBins);
+        auto raise = [&](int rank) {  // counted per bin in LDS first: <= 64 device atomics per workgroup
+          flags[o + rank] = 1;
+          atomicAdd(&s_bins[rank / binsize], 1);
+        };
+        for (int u = tid; u < Um; u += kBidThreads) {
+          const int j = llist[u];
+          const int tgt = bo.bid[o + j];
+          if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
+            if (!last) raise(a.ws.rank1[o + j]);
+            continue;
           }
-          const int rc = __popcll(__ballot(raised != 0));
-          if (rc > 0 && lane == 0)
-            __hip_atomic_fetch_add(reinterpret_cast<unsigned *>(a.ws.cnt[cur ^ 1] + b), (unsigned)rc,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // GetMax only writes max_idx when some bidder's increment is within 1e-6 of max_increments, and the
+          // reference never clears that tensor (emd_cuda.cu:181-194, emd_module.py:50: zeros): when nobody is
+          // in the window -- max_increments still holds its initial 0 and every increment is negative, i.e.
+          // eps < 0 -- Assign compares against the entry of an EARLIER iteration (initially 0).  Every bidder
+          // of a target sees the same `win`, so they all take the same branch: no read races a write.
+          int w = bo.win[o + tgt];
+          if (w >= 0)
+            a.ws.max_idx[o + tgt] = w;
+          else
+            w = a.ws.max_idx[o + tgt];
+          if (last || w == j) {
+            const int inv = a.ws.assignment_inv[o + tgt];
+            if (!last && inv != -1) {
+              a.assignment[o + inv] = -1;
+              raise(a.ws.rank1[o + inv]);  // evicted: bids again
+            }
+            a.ws.assignment_inv[o + tgt] = j;
+            a.assignment[o + j] = tgt;
+            const float np = price[o + tgt] + bo.bid_inc[o + j];
+            price[o + tgt] = np;
+            const int pos = a.ws.rank2[o + tgt];  // keep the bid phase's records in sync
+            reinterpret_cast<float *>(a.ws.t4s + o + pos)[3] = filter_target(np);
+            reinterpret_cast<float *>(a.ws.pk + o + pos)[0] = np;
+            bo.max_inc[o + tgt] = -1e9f;
+          } else {
+            raise(a.ws.rank1[o + j]);  // lost: bids again
+          }
+        }
+        __syncthreads();
+        if (tid < kRankBins) {
+          const int v = s_bins[tid];
+          if (v) {
+            __hip_atomic_fetch_add(nextbins + tid, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_bins[tid] = 0;
+          }
         }
       }
       if (a.diag) __syncthreads();
@@ -979,7 +1008,7 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
     // ---- distances of the final assignment (emd_cuda.cu:218-226), own slice of the bidder indices
     {
 #pragma clang fp contract(off)
-      for (int e = r0 + tid; e < r0 + R; e += kBidThreads) {
+      for (int e = rs0 + tid; e < rs0 + Rs; e += kBidThreads) {
         const int k = a.assignment[o + e];
         float d = 0.f;
         if (k >= 0) {
@@ -1033,8 +1062,8 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.win = reinterpret_cast<int *>(p); p += arr;
   ws.list[0] = reinterpret_cast<int *>(p); p += arr;
   ws.list[1] = reinterpret_cast<int *>(p); p += arr;
-  ws.cnt[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
-  ws.cnt[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
+  ws.bins[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
+  ws.bins[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
   ws.t4s = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
   ws.pk = reinterpret_cast<float2 *>(p); p += sn::align_up((size_t)b * n * 8, 256);
   ws.rank2 = reinterpret_cast<int *>(p); p += arr;
@@ -1057,7 +1086,7 @@ EmdWs carve(void *workspace, int b, int n) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 16 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * 4, 256) +
+  return 16 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * kRankBins * 4, 256) +
          2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
          2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
 }
