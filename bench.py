@@ -4,23 +4,35 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of the hot path over one synthetic batch PER RANK (weak scaling,
-B=32 clouds of N=16384 points each rank -- BASELINE.json configs[1] + configs[2]):
-    Chamfer distance            fwd + bwd   [32,16384,3] <-> [32,16384,3]
+One "step" = one pass of the hot path over one synthetic batch (BASELINE.json configs[1] + configs[2]):
+    Chamfer distance            fwd + bwd   [B,16384,3] <-> [B,16384,3]
     EMD (auction)               fwd + bwd   eps 0.005, 50 iterations
     expansion penalty           fwd + bwd   primitive_size 512, alpha 1.5
     ComputeDepthMaps render     fwd + bwd   8 views x radius_list, 256 x 256
     scalar losses               all-reduce (RCCL) when N > 1
+Scaling (whole clouds are independent, ranks own contiguous slices, no data-path collective):
+    --scaling weak   (default)  B = 32 clouds PER RANK, seed 1234 + rank
+    --scaling strong            ONE global batch of 32 clouds (seed 1234) split with dist_utils.shard:
+                                32 / N clouds per rank
+  At N > 1 the other mode is timed after the headline region with the same K / W and reported in
+  `other_scaling`, so one driver run per N yields both curves.
 The four parts are independent given the predicted cloud; by default the renderer runs on a second
 HIP stream next to the distance losses (config.streams = 2; --no-overlap times the one-stream step).
 After the timed region the same steps run once more one stream at a time, untimed for `value`, to
 report per-part times and the kernels' uncontended durations (roofline.isolated).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
   value             point pairs per second, whole job (CD pairs 2*B*N*M + EMD effective pairs
-                    sum_it sum_b unassigned*n, counted on the device) / wall time of the steps
+                    sum_it sum_b unassigned*n, counted on the device) / wall time of the K steps
+  ms_per_step, step_ms_percentiles_rank0   wall / K, and median / p10 / p90 of the per-step durations (HIP
+                    events on the main stream at the step boundaries)
   depthmaps_per_sec single-radius 256x256 maps per second over the same wall time
-  roofline          the dominant kernel (emd_bid): algorithmic flops / its measured launch time
-  cpu_baseline      the CPU oracle (port of the reference algorithm) on a bounded sample
+  roofline          the dominant kernel (emd_auction_kernel, one launch per EMD call): `achieved` / `frac` =
+                    algorithmic flops (14 per effective pair) / its launch time measured live with
+                    HIP events on the launch stream; `executed_*` = the work the kernel really issued
+                    (matrix-core + vector lane operations from committed PMC counters of the SAME build)
+                    over the same live time -- the pruned search skips most algorithmic pairs, so the two differ
+  cpu_baseline      the CPU oracle (port of the reference algorithm; the Chamfer single-thread leg is the
+                    reference's own CPU build when oracle/_ref is present) on a bounded sample, two legs
 """
 import argparse
 import ctypes
@@ -37,22 +49,24 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from sparenet_amd.dist_utils import reduce_mean_of_means  # noqa: E402
+from sparenet_amd.dist_utils import reduce_mean_of_means, shard  # noqa: E402
 
 B, N = 32, 16384
 EMD_EPS, EMD_ITERS = 0.005, 50
 PRIM, ALPHA = 512, 1.5
 IMG = 256
 N_VIEWS = 8
-FLOP_PER_PAIR = {"chamfer_fwd": 9.0, "emd_bid": 14.0}
-PEAK_F32_TFLOPS = 157.3                                   # MI355X_MICROARCH.md (vector == f32 MFMA peak)
+FLOP_PER_PAIR = {"chamfer_fwd": 9.0, "emd_auction": 14.0}
+PEAK_F32_TFLOPS = 157.3                                       # MI355X_MICROARCH.md (vector == f32 MFMA peak)
+N_SIMD = 256 * 4
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--radius-list", type=str, default="5,7,10",
                     help="p2i radii in pixels (reference default, configs/base_config.py:56-60); "
                          "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
@@ -62,13 +76,21 @@ def parse():
                     help="time the sequential one-stream step instead of the two-stream one")
     ap.add_argument("--no-other-ops", action="store_true",
                     help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
+    ap.add_argument("--no-other-scaling", action="store_true",
+                    help="N > 1: skip the second timed region with the other scaling mode")
     return ap.parse_args()
 
 
-def make_inputs(dev, rank):
-    g = torch.Generator().manual_seed(1234 + rank)
-    pred = torch.rand(B, N, 3, generator=g)
-    gt = torch.rand(B, N, 3, generator=g)
+def make_inputs(dev, rank, world, scaling):
+    """weak: 32 clouds per rank (seed 1234 + rank).  strong: rank's contiguous share of ONE 32-cloud batch."""
+    if scaling == "weak":
+        g = torch.Generator().manual_seed(1234 + rank)
+        pred = torch.rand(B, N, 3, generator=g)
+        gt = torch.rand(B, N, 3, generator=g)
+    else:
+        g = torch.Generator().manual_seed(1234)
+        pred = shard(torch.rand(B, N, 3, generator=g), rank, world).contiguous()
+        gt = shard(torch.rand(B, N, 3, generator=g), rank, world).contiguous()
     return pred.to(dev), gt.to(dev)
 
 
@@ -92,7 +114,6 @@ class HotPath:
         self.render = ComputeDepthMaps("orthorgonal", 1.0, IMG).to(dev)
         self.radius_list = radius_list
         self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
-        self.ev = {}
         self.last_mean_mst = None
         self.side = None
 
@@ -157,8 +178,8 @@ class HotPath:
         loss_cd.backward()
         mark("cd")
         p2 = pred.detach().requires_grad_(True)
-        dist, _ = self._emd(p2, gt)
-        loss_emd = torch.sqrt(dist).mean(1).mean()
+        dist_, _ = self._emd(p2, gt)
+        loss_emd = torch.sqrt(dist_).mean(1).mean()
         loss_emd.backward()
         mark("emd")
         return loss_cd, loss_emd, loss_exp
@@ -181,47 +202,110 @@ class HotPath:
         return losses
 
 
+def timed_region(hp, pred, gt, steps, warmup, overlap, barrier, before_timed=lambda: None):
+    """W untimed + exactly K timed steps between barrier + synchronize; returns (seconds, per-step ms, losses)."""
+    run_step = hp.step_overlapped if overlap else hp.step
+    for _ in range(warmup):
+        run_step(pred, gt)
+    barrier()
+    hp.stats.zero_()
+    before_timed()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    marks[0].record()
+    losses = None
+    for k in range(steps):
+        losses = run_step(pred, gt)
+        marks[k + 1].record()      # main stream: after the renderer's stream has been joined
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_step = [marks[k].elapsed_time(marks[k + 1]) for k in range(steps)]
+    return elapsed, per_step, losses
+
+
+def percentiles(v):
+    s = sorted(v)
+    pick = lambda q: s[min(len(s) - 1, max(0, int(round(q * (len(s) - 1)))))]
+    return {"median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "min": s[0], "max": s[-1]}
+
+
 def cpu_baseline():
-    """Time the CPU oracle (OpenMP, all host cores) on a bounded sample of the same workload."""
+    """The CPU restatement of the reference (oracle/, validated against the reference's own CPU build and its
+    golden vectors) timed on this box's host cores, on a bounded sample of the benched workload, two legs:
+    (i) one thread -- what the reference's single-threaded CPU code does (Chamfer: the reference's OWN build
+    when oracle/_ref is present); (ii) OpenMP over clouds on all cores -- best-effort CPU."""
     import numpy as np
     import oracle
 
     cores = os.cpu_count() or 1
     g = torch.Generator().manual_seed(1234)
-    pred = torch.rand(B, N, 3, generator=g).numpy()
-    gt = torch.rand(B, N, 3, generator=g).numpy()
-    nb_cd, nb_emd, nb_p2i = 32, 16, 32   # sized for ~10-30 s of CPU work on a 2-socket host
-    t0 = time.perf_counter()
-    oracle.chamfer_forward(pred[:nb_cd], gt[:nb_cd], mt=True)
-    t_cd = time.perf_counter() - t0
-    pairs_cd = 2.0 * nb_cd * N * N
-    t0 = time.perf_counter()
-    _, _, aux = oracle.emd_forward(pred[:nb_emd], gt[:nb_emd], EMD_EPS, EMD_ITERS, mt=True,
-                                   return_aux=True)
-    t_emd = time.perf_counter() - t0
-    pairs_emd = float(aux["pairs_eff"])
-    # render sample: one view, one radius, 4 clouds, through the oracle p2i (single thread)
+    pred_t = torch.rand(B, N, 3, generator=g)
+    gt_t = torch.rand(B, N, 3, generator=g)
+    pred, gt = pred_t.numpy(), gt_t.numpy()
+    radii = [5.0, 7.0, 10.0]
+
     from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
     cdm = ComputeDepthMaps("orthorgonal", 1.0, IMG)
-    data = torch.from_numpy(pred[:nb_p2i]) - 0.5
-    ij, feat = cdm.project(data, 0)
-    px = ((ij + 1) / 2 * (IMG - 1)).numpy()
-    bi = np.repeat(np.arange(nb_p2i, dtype=np.int32), N)
-    t0 = time.perf_counter()
-    oracle.p2i_max_forward(px, feat.numpy(), bi, np.zeros((nb_p2i, 1, IMG, IMG), np.float32), 5.0)
-    t_p2i = time.perf_counter() - t0
+
+    def render_inputs(nb):
+        ij, feat = cdm.project(torch.from_numpy(pred[:nb]) - 0.5, 0)
+        px = ((ij + 1) / 2 * (IMG - 1)).numpy()
+        return px, feat.numpy(), np.repeat(np.arange(nb, dtype=np.int32), N), np.zeros((nb, 1, IMG, IMG), np.float32)
+
+    def clock(fn):
+        t0 = time.perf_counter()
+        r = fn()
+        return time.perf_counter() - t0, r
+
+    # ---- leg (i): one thread
+    kind_cd = "port"
+    t_cd1 = None
+    try:
+        from oracle import ref as oref
+        if oref.available():
+            t_cd1, _ = clock(lambda: oref.chamfer_forward(pred_t[:1], gt_t[:1]))
+            kind_cd = "reference"
+    except Exception:
+        t_cd1 = None
+    if t_cd1 is None:
+        t_cd1, _ = clock(lambda: oracle.chamfer_forward(pred[:1], gt[:1]))
+    t_emd1, (_, _, aux1) = clock(lambda: oracle.emd_forward(pred[:1], gt[:1], EMD_EPS, EMD_ITERS, return_aux=True))
+    px, ft, bi, bg = render_inputs(2)
+    t_p2i1, _ = clock(lambda: [oracle.p2i_max_forward(px, ft, bi, bg, r) for r in radii])
+    single = {
+        "value": (2.0 * N * N + float(aux1["pairs_eff"])) / (t_cd1 + t_emd1),
+        "chamfer_pairs_per_sec": 2.0 * N * N / t_cd1, "chamfer_kind": kind_cd,
+        "emd_pairs_per_sec": float(aux1["pairs_eff"]) / t_emd1,
+        "depthmaps_per_sec": 2 * len(radii) / t_p2i1,
+        "sample": (f"1 thread: Chamfer fwd on 1 of 32 clouds ({kind_cd}: "
+                   + ("the reference's chamfer_distance.cpp compiled unmodified" if kind_cd == "reference" else "oracle")
+                   + f", {t_cd1:.2f} s) + EMD fwd 50 it on 1 cloud (oracle, {t_emd1:.2f} s) + "
+                   f"p2i max fwd on 2 clouds x 1 view x 3 radii (oracle, {t_p2i1:.2f} s)"),
+        # one step's forward work on one thread, extrapolated from the sample
+        "step_forward_equivalent_s": B * t_cd1 + B * t_emd1 + (B / 2.0) * N_VIEWS * t_p2i1,
+    }
+
+    # ---- leg (ii): OpenMP, all cores, all 32 clouds
+    t_cd, _ = clock(lambda: oracle.chamfer_forward(pred, gt, mt=True))
+    t_emd, (_, _, aux) = clock(lambda: oracle.emd_forward(pred, gt, EMD_EPS, EMD_ITERS, mt=True, return_aux=True))
+    px, ft, bi, bg = render_inputs(B)
+    t_p2i, _ = clock(lambda: [oracle.p2i_max_forward(px, ft, bi, bg, r, mt=True) for r in radii])
+    pairs_cd, pairs_emd = 2.0 * B * N * N, float(aux["pairs_eff"])
     return {
         "value": (pairs_cd + pairs_emd) / (t_cd + t_emd),
         "unit": "point-pairs/s",
         "cores": cores,
         "kind": "port",
-        "sample": (f"oracle (C, OpenMP x{cores} threads): Chamfer fwd on {nb_cd} of 32 clouds "
-                   f"({pairs_cd:.3g} pairs, {t_cd:.2f} s) + EMD fwd eps {EMD_EPS} iters {EMD_ITERS} on "
-                   f"{nb_emd} cloud ({pairs_emd:.3g} effective pairs, {t_emd:.2f} s); "
-                   f"p2i max fwd R=5 on {nb_p2i} clouds x 1 view, 1 thread: {t_p2i:.2f} s"),
-        "depthmaps_per_sec_1thread": nb_p2i / t_p2i,
+        "sample": (f"oracle (C, OpenMP x{cores} threads) on the benched batch: Chamfer fwd 32 clouds "
+                   f"({pairs_cd:.3g} pairs, {t_cd:.2f} s) + EMD fwd eps {EMD_EPS} iters {EMD_ITERS} 32 clouds "
+                   f"({pairs_emd:.3g} effective pairs, {t_emd:.2f} s) + p2i max fwd 32 clouds x 1 of 8 views x 3 "
+                   f"radii, clouds in parallel ({t_p2i:.2f} s)"),
         "chamfer_pairs_per_sec": pairs_cd / t_cd,
         "emd_pairs_per_sec": pairs_emd / t_emd,
+        "depthmaps_per_sec": B * len(radii) / t_p2i,
+        "step_forward_equivalent_s": t_cd + t_emd + N_VIEWS * t_p2i,
+        "single_thread": single,
     }
 
 
@@ -301,6 +385,21 @@ def other_ops(dev, pred, mean_mst):
     return out
 
 
+def committed_counters(build_id, kernel):
+    """Hardware counters of `kernel` from the newest profiles/*pmc*.json taken on THIS build of the library
+    (tools/pmc_all.sh stamps sn_build_id into the file); None if there is none -- counters of other code are
+    never quoted."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_build_id") == build_id and kernel in d:
+            best = (os.path.basename(f), d[kernel])
+    return best
+
+
 def main():
     args = parse()
     radius_list = [float(r) for r in args.radius_list.split(",")]
@@ -315,11 +414,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("nccl", rank=rank, world_size=world)
-    n_gpus = world
+    if B % world:
+        raise SystemExit(f"the strong split shards {B} clouds: world size {world} must divide it")
 
-    pred, gt = make_inputs(dev, rank)
+    pred, gt = make_inputs(dev, rank, world, args.scaling)
+    b_local = pred.size(0)
     hp = HotPath(dev, radius_list)
     lib = hp.lib.lib()
+    build_id = lib.sn_build_id().decode()
 
     def barrier():
         if world > 1:
@@ -327,27 +429,19 @@ def main():
         torch.cuda.synchronize()
 
     overlap = not args.no_overlap
-    run_step = hp.step_overlapped if overlap else hp.step
-    for _ in range(args.warmup):
-        run_step(pred, gt)
-    barrier()
-    hp.stats.zero_()
-    timers = []
-    if not args.no_roofline:
-        lib.sn_prof_reset()
-        lib.sn_prof_enable(1)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        losses = run_step(pred, gt, timers) if not overlap else run_step(pred, gt)
-    barrier()
-    elapsed = time.perf_counter() - t0
+
+    def prof_on():   # the in-library launch timers cover exactly the timed steps
+        if not args.no_roofline:
+            lib.sn_prof_reset()
+            lib.sn_prof_enable(1)
+
+    elapsed, per_step, losses = timed_region(hp, pred, gt, args.steps, args.warmup, overlap, barrier, prof_on)
     lib.sn_prof_enable(0)
     stats_timed = hp.stats.clone()
 
     def read_kernels():
         ks = {}
-        for kname in ("chamfer_fwd", "emd_bid", "emd_auction", "expansion_fwd", "p2i_max_splat"):
+        for kname in ("chamfer_fwd", "emd_auction", "expansion_fwd", "p2i_max_splat"):
             ms = ctypes.c_double(0.0)
             cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
             ks[kname] = {"launches": int(cnt), "total_ms": ms.value,
@@ -357,16 +451,17 @@ def main():
     kernels = read_kernels() if not args.no_roofline else {}
     # outside the timed region: the same steps one stream at a time, for the per-part times and for
     # the kernels' uncontended durations
-    kernels_isolated, isolated_ms = {}, None
-    if overlap and not args.no_roofline:
+    kernels_isolated, isolated_ms, timers = {}, None, []
+    iso_steps = min(args.steps, 10)
+    if not args.no_roofline:
         lib.sn_prof_reset()
         lib.sn_prof_enable(1)
         barrier()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(iso_steps):
             hp.step(pred, gt, timers)
         barrier()
-        isolated_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        isolated_ms = (time.perf_counter() - t1) / iso_steps * 1e3
         lib.sn_prof_enable(0)
         kernels_isolated = read_kernels()
     hp.stats.copy_(stats_timed)
@@ -377,9 +472,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(pairs_emd, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    pairs_cd = 2.0 * B * N * N * args.steps * world
+    pairs_cd = 2.0 * b_local * N * N * args.steps * world
     pairs_total = pairs_cd + float(pairs_emd.item())
-    maps_total = B * N_VIEWS * len(radius_list) * args.steps * world
+    maps_total = b_local * N_VIEWS * len(radius_list) * args.steps * world
+
+    # the other scaling mode, same K / W (N > 1 only): one driver run per N gives both curves
+    other = None
+    if world > 1 and not args.no_other_scaling:
+        mode2 = "strong" if args.scaling == "weak" else "weak"
+        p2_, g2_ = make_inputs(dev, rank, world, mode2)
+        e2, ps2, _ = timed_region(hp, p2_, g2_, args.steps, args.warmup, overlap, barrier)
+        t2 = torch.tensor([e2], dtype=torch.float64, device=dev)
+        pe2 = hp.stats[0:1].to(torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pe2, op=dist.ReduceOp.SUM)
+        bl2 = p2_.size(0)
+        other = {
+            "scaling": mode2, "batch_per_gpu": bl2, "global_batch": bl2 * world,
+            "value": (2.0 * bl2 * N * N * args.steps * world + float(pe2.item())) / float(t2.item()),
+            "depthmaps_per_sec": bl2 * N_VIEWS * len(radius_list) * args.steps * world / float(t2.item()),
+            "ms_per_step": float(t2.item()) / args.steps * 1e3,
+            "step_ms_percentiles_rank0": percentiles(ps2),
+        }
+        del p2_, g2_
 
     # per-segment times on rank 0 (torch events on the current stream)
     seg = {}
@@ -388,71 +503,94 @@ def main():
         if name == "start":
             continue
         seg[name] = seg.get(name, 0.0) + timers[i - 1][1].elapsed_time(ev)
-    seg = {k: v / args.steps for k, v in seg.items()}
+    seg = {k: v / iso_steps for k, v in seg.items()}
 
     roofline = None
     if not args.no_roofline:
-        bid = kernels["emd_auction"] if kernels["emd_auction"]["launches"] else kernels["emd_bid"]
-        if bid["launches"]:
-            flops = FLOP_PER_PAIR["emd_bid"] * float(hp.stats[0].item())     # this rank
-            achieved = flops / (bid["total_ms"] * 1e-3) / 1e12
-            traffic = None   # PMC passes cannot run inside the bench: committed measurement
-            tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_emd_bid_traffic.json")))
-            if tfiles:   # the newest committed PMC measurement (tools/traffic_emd.sh)
-                traffic = json.load(open(tfiles[-1])).get("bytes_per_launch_corrected")
+        auc = kernels["emd_auction"]
+        if auc["launches"]:
+            pairs_rank = float(stats_timed[0].item())
+            flops = FLOP_PER_PAIR["emd_auction"] * pairs_rank                # this rank, algorithmic
+            dur = auc["total_ms"] * 1e-3
+            achieved = flops / dur / 1e12
             roofline = {
-                "kernel": "emd_bid_kernel", "bound": "mfma", "achieved": achieved,
+                "kernel": "emd_auction_kernel", "bound": "mfma", "achieved": achieved,
                 "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": traffic,
-                "note": ("pairwise search, 14 flop/pair x effective pairs (SURVEY 8d) over the bid "
-                         "launches; peak = f32 vector = f32 MFMA dense peak 157.3 TFLOP/s. The "
-                         "kernel filters pairs on the fp32 matrix cores and skips superblocks of "
-                         "targets by bounding box, so part of the algorithmic pairs is never "
-                         "evaluated"),
-                "launches": bid["launches"], "avg_launch_us": bid["avg_us"],
-                "pairs_per_launch_avg": float(hp.stats[0].item()) / bid["launches"],
+                "algorithmic_frac": achieved / PEAK_F32_TFLOPS,
+                "traffic": None,
+                "timing": "live: HIP events on the launch stream inside the timed region (the renderer contends on "
+                          "the second stream); `isolated` = the same launches one stream at a time",
+                "note": ("pairwise search: `achieved` = 14 flop x effective pairs (SURVEY 8d) / launch time, an "
+                         "ALGORITHMIC rate -- the kernel skips target blocks by bounding box and filters pairs on "
+                         "the fp32 matrix cores, so most algorithmic pairs are never evaluated and the rate is not "
+                         "bounded by the peak; `executed_frac` is the issued work over the same time. peak = f32 "
+                         "vector = f32 MFMA dense peak"),
+                "launches": auc["launches"], "avg_launch_us": auc["avg_us"],
+                "pairs_per_launch_avg": pairs_rank / auc["launches"],
             }
-            iso = kernels_isolated.get("emd_auction") if kernels_isolated.get("emd_auction", {}).get("launches") else kernels_isolated.get("emd_bid")
+            pmc = committed_counters(build_id, "emd_auction_kernel")
+            if pmc:
+                fname, c = pmc
+                m = lambda k: c.get(k, {}).get("mean")
+                mops, valu, gui = m("SQ_INSTS_VALU_MFMA_MOPS_F32"), m("SQ_INSTS_VALU"), m("GRBM_GUI_ACTIVE")
+                if mops is not None and valu is not None:
+                    ex = mops * 512.0 + valu * 64.0          # matrix-core flops + vector lane operations per launch
+                    ex_rate = ex * auc["launches"] / dur / 1e12
+                    roofline["executed_flops_per_launch"] = ex
+                    roofline["executed_tflops"] = ex_rate
+                    roofline["executed_frac"] = ex_rate / PEAK_F32_TFLOPS
+                if gui:
+                    simd_cycles = gui / 8.0 * N_SIMD          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                    if m("SQ_ACTIVE_INST_VALU") is not None:
+                        roofline["valu_busy"] = m("SQ_ACTIVE_INST_VALU") * 4.0 / simd_cycles   # quad-cycles
+                    if m("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                        roofline["mfma_busy"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles
+                if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
+                    # KB per launch; x2 on FETCH_SIZE: the guide's gfx950 correction for wide coalesced reads
+                    roofline["traffic"] = (2.0 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024.0
+                roofline["counters_from"] = f"profiles/{fname} (build {build_id})"
+            else:
+                roofline["counters_from"] = (f"none: no profiles/*pmc*.json was taken on build {build_id} "
+                                             "(tools/pmc_all.sh); counters of other code are not quoted")
+            iso = kernels_isolated.get("emd_auction")
             if iso and iso["launches"]:
-                ach = flops / (iso["total_ms"] * 1e-3) / 1e12
-                roofline["isolated"] = {
-                    "achieved": ach, "frac": ach / PEAK_F32_TFLOPS, "avg_launch_us": iso["avg_us"],
-                    "note": ("the same steps run one stream at a time after the timed region; in the "
-                             "timed region the renderer runs on a second stream next to the auction "
-                             "and every kernel's duration includes that contention")}
+                ach = (FLOP_PER_PAIR["emd_auction"] * pairs_rank / args.steps * iso_steps
+                       / (iso["total_ms"] * 1e-3) / 1e12)
+                roofline["isolated"] = {"achieved": ach, "frac": ach / PEAK_F32_TFLOPS,
+                                        "avg_launch_us": iso["avg_us"]}
             cf = kernels["chamfer_fwd"]
             if cf["launches"]:
-                roofline["chamfer_fwd"] = {
-                    "achieved": FLOP_PER_PAIR["chamfer_fwd"] * 2.0 * B * N * N * cf["launches"]
-                    / (cf["total_ms"] * 1e-3) / 1e12,
-                    "avg_launch_us": cf["avg_us"]}
-                roofline["chamfer_fwd"]["frac"] = roofline["chamfer_fwd"]["achieved"] / PEAK_F32_TFLOPS
-                roofline["chamfer_fwd"]["note"] = (
-                    "sort + box-pruned search: 9 flop x ALL n*m pairs / launch time; most pairs are "
-                    "never evaluated, so this algorithmic rate may exceed the all-pairs roofline")
+                a = (FLOP_PER_PAIR["chamfer_fwd"] * 2.0 * b_local * N * N * cf["launches"]
+                     / (cf["total_ms"] * 1e-3) / 1e12)
+                roofline["chamfer_fwd"] = {"achieved": a, "algorithmic_frac": a / PEAK_F32_TFLOPS,
+                                           "avg_launch_us": cf["avg_us"],
+                                           "note": "sort + box-pruned search: 9 flop x ALL n*m pairs / launch time"}
 
     if rank == 0:
         out = {
             "metric": "point-pairs/sec (CD+EMD) + depthmaps/sec, B=32 N=16384",
             "value": pairs_total / elapsed,
             "unit": "point-pairs/s",
-            "n_gpus": n_gpus,
+            "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "depthmaps_per_sec": maps_total / elapsed,
+            "step_ms_percentiles_rank0": percentiles(per_step),
             "config": {
-                "workload": ("per rank: CD fwd+bwd + EMD(eps 0.005, 50 it) fwd+bwd + expansion(P=512, "
-                             "alpha 1.5) fwd+bwd on [32,16384,3]; ComputeDepthMaps 8 views x radii "
+                "workload": (f"per rank: CD fwd+bwd + EMD(eps 0.005, 50 it) fwd+bwd + expansion(P=512, "
+                             f"alpha 1.5) fwd+bwd on [{b_local},16384,3]; ComputeDepthMaps 8 views x radii "
                              f"{radius_list} px -> 256x256 fwd+bwd; scalar-loss all-reduce"),
-                "batch_per_gpu": B, "points": N, "emd_iters": EMD_ITERS, "radius_list": radius_list,
-                "image": IMG, "views": N_VIEWS, "streams": 2 if overlap else 1,
+                "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
+                "emd_iters": EMD_ITERS, "radius_list": radius_list,
+                "image": IMG, "views": N_VIEWS, "streams": 2 if overlap else 1, "library_build": build_id,
             },
+            "other_scaling": other,
             "pairs_per_step": pairs_total / args.steps / world,
             "maps_per_step": maps_total / args.steps / world,
             "segments_ms_rank0": seg,
@@ -465,7 +603,13 @@ def main():
         if world == 1 and not args.no_other_ops:
             out["other_ops_ms_rank0"] = other_ops(dev, pred, hp.last_mean_mst)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            cb = cpu_baseline()
+            # the north star's combined ratio: one step's forward work, CPU over the GPU's whole step
+            cb["gpu_step_ms"] = elapsed / args.steps * 1e3
+            cb["combined_speedup_vs_all_cores"] = cb["step_forward_equivalent_s"] / (elapsed / args.steps)
+            cb["combined_speedup_vs_one_thread"] = (cb["single_thread"]["step_forward_equivalent_s"]
+                                                    / (elapsed / args.steps))
+            out["cpu_baseline"] = cb
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -37,6 +37,8 @@ extern "C" {
 #define SN_ABI_VERSION 1
 
 int sn_abi_version(void);
+/* hash of the HIP sources this library was built from (profiles/ measurements carry it) */
+const char *sn_build_id(void);
 /* thread-local text of the last failure on the calling thread ("" if none) */
 const char *sn_last_error(void);
 

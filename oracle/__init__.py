@@ -169,7 +169,7 @@ def gather_backward(grad_out, idx, n):
 
 
 # ------------------------------------------------------------------------- p2i
-def p2i_max_forward(points, feat, batch_inds, background, radius):
+def p2i_max_forward(points, feat, batch_inds, background, radius, mt=False):
     points, pp = _f(points)
     feat, pf = _f(feat)
     bi, pb = _i(batch_inds)
@@ -178,8 +178,8 @@ def p2i_max_forward(points, feat, batch_inds, background, radius):
     n = points.shape[0]
     out = bg.copy()
     ids = np.full((B, C, H, W), -1, np.int32)
-    lib().oracle_p2i_max_forward(pp, pf, pb, n, C, B, H, W, ctypes.c_float(radius),
-                                 _pf(out), _pi(ids))
+    fn = lib().oracle_p2i_max_forward_mt if mt else lib().oracle_p2i_max_forward
+    fn(pp, pf, pb, n, C, B, H, W, ctypes.c_float(radius), _pf(out), _pi(ids))
     return out, ids
 
 

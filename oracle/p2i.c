@@ -62,6 +62,34 @@ void oracle_p2i_max_forward(const float *points, const float *feat, const int *b
   }
 }
 
+/* The same splat with the images of different clouds painted by different threads: points are visited
+ * in ascending id inside every cloud, so every pixel sees exactly the sequence of candidates it sees in
+ * oracle_p2i_max_forward (bit-identical output; bench.py's multi-threaded CPU baseline). */
+void oracle_p2i_max_forward_mt(const float *points, const float *feat, const int *batch_inds,
+                               int npoints, int channels, int batch, int h, int w, float radius,
+                               float *out, int *out_ids) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int bb = 0; bb < batch; ++bb)
+    for (int id = 0; id < npoints * channels; ++id) {
+      const int c = id % channels, pid = (id / channels) % npoints;
+      if (batch_inds[pid] != bb) continue;
+      const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+      const box_t bx = box_of(py, px, h, w, radius);
+      for (int x = bx.min_x; x <= bx.max_x; ++x)
+        for (int y = bx.min_y; y <= bx.max_y; ++y) {
+          const float dx = x - px, dy = y - py;
+          const float r = sqrtf(dx * dx + dy * dy);
+          if (!(r <= radius)) continue;
+          const size_t index = (((size_t)bb * channels + c) * h + y) * w + x;
+          const float v = feat[id] * cos_weight(r, radius);
+          if (out[index] < v) {
+            out[index] = v;
+            out_ids[index] = pid;
+          }
+        }
+    }
+}
+
 void oracle_p2i_max_backward(const float *out_grad, const int *out_ids, const float *points,
                              const float *feat, int npoints, int channels, int batch, int h,
                              int w, float radius, float *points_grad, float *feat_grad,

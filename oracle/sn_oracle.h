@@ -87,6 +87,10 @@ void oracle_p2i_max_forward(const float *points, const float *feat,
                             const int *batch_inds, int npoints, int channels,
                             int batch, int h, int w, float radius, float *out,
                             int *out_ids);
+void oracle_p2i_max_forward_mt(const float *points, const float *feat,
+                            const int *batch_inds, int npoints, int channels,
+                            int batch, int h, int w, float radius, float *out,
+                            int *out_ids);
 void oracle_p2i_max_backward(const float *out_grad, const int *out_ids,
                              const float *points, const float *feat,
                              int npoints, int channels, int batch, int h,

@@ -30,6 +30,7 @@ def lib():
                 "g.build()'` or `make -C sparenet_amd/csrc`. sparenet_amd has no CPU fallback.")
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.sn_last_error.restype = ctypes.c_char_p
+        _lib.sn_build_id.restype = ctypes.c_char_p
         _lib.sn_prof_read.restype = ctypes.c_longlong
         _lib.sn_prof_enable.restype = None
         _lib.sn_prof_reset.restype = None

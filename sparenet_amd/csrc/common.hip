@@ -91,5 +91,9 @@ extern "C" void sn_prof_reset(void) {
   sn::g_open.clear();
 }
 
+#ifndef SN_BUILD_ID
+#define SN_BUILD_ID "unknown"
+#endif
 extern "C" int sn_abi_version(void) { return SN_ABI_VERSION; }
+extern "C" const char *sn_build_id(void) { return SN_BUILD_ID; }
 extern "C" const char *sn_last_error(void) { return sn::last_error_buf(); }

@@ -921,9 +921,6 @@ __global__ __launch_bounds__(kBidThreads, 4) void emd_auction_kernel(AuctionArgs
         const int ngroups = (Um + 63) >> 6;
         int S = 1;
         while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
-#ifdef SN_EMD_SEQ_MAX
-        if (ngroups <= SN_EMD_SEQ_MAX) S = kBidWaves;  // A/B: few groups one after the other, 16 waves each
-#endif
         const int gpb = kBidWaves / S;
         const int seg = wave & (S - 1), gslot = wave / S;
         for (int q0 = 0; q0 < ngroups; q0 += gpb) {

@@ -74,6 +74,19 @@ def test_depthmaps_host_glue_vs_reference(golden_dir, monkeypatch):
     assert p2i_utils.N_VIEWS_PREDEFINED == 8
 
 
+def test_oracle_mt_splat_equals_sequential():
+    """bench.py's multi-threaded CPU baseline (clouds painted in parallel) is the sequential splat bit for bit."""
+    rng = np.random.default_rng(0)
+    B, n, S = 5, 3000, 80
+    pts = ((rng.random((B * n, 2), dtype=np.float32) * 1.1 - 0.05) * (S - 1)).astype(np.float32)
+    feat = rng.random((B * n, 1), dtype=np.float32)
+    bi = rng.integers(-1, B + 1, B * n).astype(np.int32)
+    bg = np.full((B, 1, S, S), 0.01, np.float32)
+    a = oracle.p2i_max_forward(pts, feat, bi, bg, 6.0)
+    b = oracle.p2i_max_forward(pts, feat, bi, bg, 6.0, mt=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 # ------------------------------------------------------------------ GPU side
 def _close_maps(out, ids, ref_out, ref_ids, what):
     np.testing.assert_allclose(out, ref_out, rtol=2e-6, atol=1e-7, err_msg=what)

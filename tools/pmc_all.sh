@@ -15,7 +15,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmcD -- python $R/$PROBE > /dev/null 2>&1
 cd $R
 python - "$OUT" <<'PY'
-import csv, glob, json, subprocess, sys
+import csv, glob, json, sys
 kernels = ["emd_bid_kernel", "emd_auction_kernel", "emd_assign_kernel", "emd_compact_kernel", "emd_getmax_kernel",
            "nn_search_kernel", "chamfer_bwd_scatter_kernel", "chamfer_bwd_own_kernel", "expansion_fwd_kernel",
            "p2i_gather_max_kernel", "p2i_max_bwd_accum_kernel", "p2i_bin_scatter_kernel", "mds_clustered_kernel"]
@@ -36,10 +36,11 @@ for d in ("pmcA", "pmcB", "pmcC", "pmcD"):
         v = list(per.values())
         res[k][c] = {"mean": sum(v) / len(v), "max": max(v), "min": min(v), "dispatches": len(v)}
 res = {k: v for k, v in res.items() if v}
-try:
-    res["_commit"] = subprocess.check_output(["git", "rev-parse", "--short", "HEAD"], text=True).strip()
-except Exception:
-    pass
+import ctypes
+lib = ctypes.CDLL("sparenet_amd/libsparenet_hip.so")
+lib.sn_build_id.restype = ctypes.c_char_p
+res["_build_id"] = lib.sn_build_id().decode()   # bench.py only quotes counters taken on the build it runs
+res["_units"] = "per-dispatch means; FETCH_SIZE / WRITE_SIZE in KB; SQ_ACTIVE_* / SQ_WAIT_* / SQ_WAVE_CYCLES in quad-cycles; GRBM_GUI_ACTIVE summed over the 8 XCDs"
 json.dump(res, open(sys.argv[1], "w"), indent=1)
 for k, v in res.items():
     if isinstance(v, dict):
