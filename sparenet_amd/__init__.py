@@ -9,3 +9,33 @@ include/sparenet_hip.h.  There is no CPU or eager-PyTorch fallback.
 from ._lib import LIB_PATH, SparenetHipError, lib  # noqa: F401
 
 __version__ = "0.1.0"
+
+_REFERENCE_OP_PACKAGES = ("chamfer_distance", "chamfer_dist", "emd", "expansion_penalty", "MDS", "p2i_op",
+                          "gridding", "gridding_loss", "cubic_feature_sampling")
+
+
+def alias_reference_modules():
+    """Make the reference's import lines resolve to this package without touching its checkout:
+    `from cuda.emd.emd_module import emdModule` (runners/sparenet_runner.py:9), `import cuda.MDS.MDS_module`
+    (models/sparenet_generator.py:8), `from cuda.p2i_op import p2i`, `from utils.p2i_utils import
+    ComputeDepthMaps` (utils/model_init.py:9) ... -- INTEGRATION.md section 2.  Call it once at start-up,
+    before the runners are imported."""
+    import importlib
+    import sys
+
+    amd_cuda = importlib.import_module("sparenet_amd.cuda")
+    sys.modules["cuda"] = amd_cuda
+    for name in _REFERENCE_OP_PACKAGES:
+        mod = importlib.import_module(f"sparenet_amd.cuda.{name}")
+        sys.modules[f"cuda.{name}"] = mod
+        for sub in ("emd_module", "expansion_penalty_module", "MDS_module", "chamfer_distance"):
+            try:
+                sys.modules[f"cuda.{name}.{sub}"] = importlib.import_module(f"sparenet_amd.cuda.{name}.{sub}")
+            except ModuleNotFoundError:
+                pass
+    amd_p2i = importlib.import_module("sparenet_amd.utils.p2i_utils")
+    sys.modules["utils.p2i_utils"] = amd_p2i
+    utils_pkg = sys.modules.get("utils")
+    if utils_pkg is not None:                 # the reference's own `utils` package, already imported
+        setattr(utils_pkg, "p2i_utils", amd_p2i)
+    return amd_cuda

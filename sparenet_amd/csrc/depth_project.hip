@@ -26,11 +26,14 @@ __device__ __forceinline__ float unord_bits(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// The reference multiplies the 4x4 matrix with [x y z 1]^T as a batched matrix product
+// (utils/p2i_utils.py:153-165); its CPU execution -- what the golden vectors were generated with --
+// accumulates left to right with separately rounded products and sums, and so does this.
 __device__ __forceinline__ void transform(const Mat4 &M, float x, float y, float z, float o[4]) {
+#pragma clang fp contract(off)
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    o[r] = __builtin_fmaf(M.m[r * 4 + 2], z, __builtin_fmaf(M.m[r * 4 + 1], y, M.m[r * 4] * x)) +
-           M.m[r * 4 + 3];
+    o[r] = ((M.m[r * 4] * x + M.m[r * 4 + 1] * y) + M.m[r * 4 + 2] * z) + M.m[r * 4 + 3];
 }
 
 // 1024-thread blocks, at most 128 of them: every block ends with two same-address atomics, which
@@ -173,8 +176,9 @@ extern "C" int sn_depth_project_forward(const float *data, long npoints, const f
   SN_REQUIRE(matrix16 && zminmax, "sn_depth_project_forward: null pointer");
   SN_REQUIRE(npoints >= 0, "sn_depth_project_forward: npoints < 0");
   hipStream_t s = sn::as_stream(stream);
-  const unsigned init[2] = {0xffffffffu, 0u};
-  SN_HIP(hipMemcpyAsync(zminmax, init, 8, hipMemcpyHostToDevice, s));
+  // {min key, max key} = {0xffffffff, 0}: two memset nodes, no pageable host copy (capturable, never blocks)
+  SN_HIP(hipMemsetAsync(zminmax, 0xff, 4, s));
+  SN_HIP(hipMemsetAsync(zminmax + 1, 0, 4, s));
   if (npoints == 0) return 0;
   SN_REQUIRE(data && pixel && z && feat, "sn_depth_project_forward: null pointer");
   Mat4 M;

@@ -114,13 +114,19 @@ class Completion(torch.nn.Module):
         side = self._side
         coarse = generator.coarse
         part = partial.transpose(1, 2).contiguous()
+        # tensors that cross streams are registered with the caching allocator (record_stream): without it
+        # a block freed on its own stream may be handed out again while the other stream still reads it
+        gt.record_stream(side)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             coarse_loss = self._metric(coarse, gt)
+        coarse_loss.record_stream(main)
         middle, expansion_penalty = generator.refine1(coarse.transpose(1, 2).contiguous(), part, coarse)
+        middle.record_stream(side)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             middle_loss = self._metric(middle, gt)
+        middle_loss.record_stream(main)
         refine, _ = generator.refine2(middle.transpose(1, 2).contiguous(), part, middle)
         refine_loss = self._metric(refine, gt)
         main.wait_stream(side)

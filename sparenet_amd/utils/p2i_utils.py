@@ -13,7 +13,9 @@ What forward() computes, per view (reference :211-252):
     output   = cat_r map_r  -> [B, len(radius_list), S, S]
 The camera matrices are evaluated with the same fp32 torch operations as the reference
 so the eight P@V matrices agree bit for bit (tests/golden/depthmaps_*.npz); the
-per-point transform is a [B*N,3]x[3,4] product instead of B*N expanded 4x4 bmm's.
+per-point transform is evaluated in the order of the reference's batched 4x4 product
+(left to right, separately rounded), so projected coordinates and depth features are
+bit-equal to the imported reference's.
 """
 import ctypes
 import math
@@ -90,7 +92,12 @@ def transform(matrix, points):
         hom = torch.cat([points, torch.ones_like(points[:, :1])], dim=1).unsqueeze(-1)
         out = (matrix @ hom).squeeze(-1)
     else:
-        out = points @ matrix[:, :3].t() + matrix[:, 3]
+        # one matrix for all points: the same left-to-right sum of separately rounded products the
+        # reference's batched product evaluates on the CPU (and depth_project.hip on the GPU), without
+        # materialising npoints copies of the matrix
+        x, y, z = points[:, 0:1], points[:, 1:2], points[:, 2:3]
+        m = matrix
+        out = ((m[:, 0] * x + m[:, 1] * y) + m[:, 2] * z) + m[:, 3]
     return out[:, :3] / out[:, 3:4]
 
 

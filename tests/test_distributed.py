@@ -6,6 +6,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -58,3 +59,43 @@ def test_world2_gloo_loss_allreduce(tmp_path):
     d1, d2, _, _ = oracle.chamfer_forward(pred.numpy(), gt.numpy())
     np.testing.assert_allclose(r0[0], d1.mean() + d2.mean(), rtol=1e-6)
     assert r0[1] == 2.0  # each rank owned 2 of the 4 clouds
+
+
+@pytest.mark.gpu
+def test_sharded_step_equals_unsharded_on_the_product_path(dev):
+    """SURVEY 8(e) on the HIP ops themselves (one process standing in for the ranks, one after the other):
+    the losses of shard(pred, r, world) averaged over the ranks (what the all-reduce produces) equal the
+    unsharded batch's -- every op is independent per cloud.  ComputeDepthMaps is the documented exception:
+    its depth feature is normalised by the z range of the LOCAL tensor (utils/p2i_utils.py:226), so a
+    shard's maps differ from the corresponding slice of the whole batch's maps, exactly as under the
+    reference's DataParallel."""
+    from sparenet_amd.cuda.chamfer_distance import ChamferDistance
+    from sparenet_amd.cuda.emd.emd_module import emdModule
+    from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
+    from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
+
+    world = 4
+    g = torch.Generator().manual_seed(1234)
+    pred = torch.rand(8, 2048, 3, generator=g).to(dev)
+    gt = torch.rand(8, 2048, 3, generator=g).to(dev)
+    render = ComputeDepthMaps("orthorgonal", 1.0, 64).to(dev)
+
+    def losses(p, q):
+        d1, d2 = ChamferDistance()(p, q)
+        dist, _ = emdModule()(p, q, eps=0.005, iters=20)
+        pen, _, _ = expansionPenaltyModule()(p, 256, 1.5)
+        return torch.stack([d1.mean() + d2.mean(), torch.sqrt(dist).mean(1).mean(), pen.mean()]).double()
+
+    whole = losses(pred, gt)
+    parts = torch.stack([losses(shard(pred, r, world).contiguous(), shard(gt, r, world).contiguous())
+                         for r in range(world)])
+    np.testing.assert_allclose(parts.mean(0).cpu().numpy(), whole.cpu().numpy(), rtol=2e-6)
+    # per-cloud results themselves are identical, not just their means
+    d_whole, a_whole = emdModule()(pred, gt, eps=0.005, iters=20)
+    lo, hi = shard_bounds(8, 2, world)
+    d_part, a_part = emdModule()(pred[lo:hi].contiguous(), gt[lo:hi].contiguous(), eps=0.005, iters=20)
+    assert torch.equal(a_whole[lo:hi], a_part) and torch.equal(d_whole[lo:hi], d_part)
+    maps_whole = render(pred - 0.5, view_id=1, radius_list=[5.0])
+    maps_part = render((pred - 0.5)[lo:hi].contiguous(), view_id=1, radius_list=[5.0])
+    assert not torch.equal(maps_whole[lo:hi], maps_part)          # local z-range normalisation
+    assert (maps_whole[lo:hi] > 0).eq(maps_part > 0).all()        # same footprints, different depth scale
