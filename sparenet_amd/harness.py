@@ -21,9 +21,14 @@ generator, not in the loss) and to exercise autograd through the whole chain.
 
 `GanStep` adds the adversarial half (runners/sparenet_gan_runner.py:69-113 train_step, :186-266 discriminator
 update, :268-347 generator update): the middle cloud, the ground truth and the partial input are rendered from
-all 8 views at one radius drawn from the list, the 8+8 maps go through a discriminator (here a bf16 stride-2
-conv surrogate with the reference's feature-map shapes), LSGAN targets, feature matching weighted by channel
-count, L1 image matching, and errG = 200 rec + 0.1 gan + fm + im (configs/base_config.py:67-73).
+all 8 views at one radius drawn from the list, the 8+8 maps go through a discriminator
+(sparenet_amd.networks.PatchDiscriminator), LSGAN targets, feature matching weighted by channel count, L1 image
+matching, and errG = 200 rec + 0.1 gan + fm + im (configs/base_config.py:67-73).
+
+The learned networks themselves (EdgeConv encoder, style-based folding decoder, residual refiners,
+discriminators) and the objectives as plain functions live in sparenet_amd/networks.py; `Completion` and
+`GanStep` accept either generator (`SurrogateGenerator` here for op-level timing, `networks.Generator` for
+BASELINE configs 4-5).
 """
 import random
 
@@ -35,7 +40,8 @@ from sparenet_amd.cuda.chamfer_distance import ChamferDistance, ChamferDistanceM
 from sparenet_amd.cuda.emd.emd_module import emdModule
 from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
 from sparenet_amd.cuda.MDS import MDS_module
-from sparenet_amd.cuda.knn import get_graph_feature
+from sparenet_amd.networks import (completion_loss, discriminator_objective, emd_term, feature_matching,
+                                   generator_objective)
 
 
 class SurrogateRefine(torch.nn.Module):
@@ -95,7 +101,7 @@ class Completion(torch.nn.Module):
         if self.metric == "chamfer":
             return self.chamfer_dist_mean(cloud, gt).mean()
         dist, _ = self.emd_dist(cloud, gt, eps=0.005, iters=50)
-        return torch.sqrt(dist).mean(1).mean()
+        return emd_term(dist)
 
     def forward(self, generator, partial, gt):
         if self.overlap and partial.is_cuda and isinstance(generator, SurrogateGenerator):
@@ -133,34 +139,9 @@ class Completion(torch.nn.Module):
         return self._compose(coarse, middle, refine, expansion_penalty, coarse_loss, middle_loss, refine_loss, gt)
 
     def _compose(self, coarse, middle, refine, expansion_penalty, coarse_loss, middle_loss, refine_loss, gt):
-        loss = coarse_loss + middle_loss + refine_loss + expansion_penalty.mean() * 0.1
-        if self.use_consist_loss:
-            dist1, _ = self.chamfer_dist(refine, gt)
-            loss = loss + torch.mean(dist1).mean() * 0.5
+        dist1 = self.chamfer_dist(refine, gt)[0] if self.use_consist_loss else None
+        loss = completion_loss(coarse_loss, middle_loss, refine_loss, expansion_penalty, dist1)
         return loss, refine, middle, coarse, refine_loss, coarse_loss
-
-
-class SurrogateDiscriminator(torch.nn.Module):
-    """Shapes of PatchDiscriminator (models/sparenet_discriminator.py:13-81): [B,2V,S,S] -> validity [B,1]
-    and, with feat=True, the first four feature maps (16,32,64,128 channels at S/2..S/16).  Plain
-    stride-2 convolutions + LeakyReLU under bf16 autocast; no spectral norm, no batch norm."""
-
-    def __init__(self, img_shape=(2 * N_VIEWS_PREDEFINED, 256, 256)):
-        super().__init__()
-        widths = [img_shape[0], 16, 32, 64, 128, 256, 512]
-        self.blocks = torch.nn.ModuleList(
-            torch.nn.Conv2d(widths[i], widths[i + 1], 4, stride=2, padding=1) for i in range(6))
-        self.adv_layer = torch.nn.Conv2d(512, 1, 3, padding=1, bias=False)
-
-    def forward(self, img, feat=False, y=None):
-        feats, x = [], img
-        with torch.autocast(img.device.type, dtype=torch.bfloat16):
-            for conv in self.blocks:
-                x = torch.nn.functional.leaky_relu(conv(x), 0.2)
-                feats.append(x)
-            validity = self.adv_layer(x)
-        validity = validity.float().mean(dim=(2, 3)).view(img.shape[0], -1)
-        return (validity, [f.float() for f in feats[:4]]) if feat else validity
 
 
 class GanStep:
@@ -175,7 +156,6 @@ class GanStep:
         self.use_fm, self.use_im = use_fm, use_im
         self.weight_l2, self.weight_gan, self.weight_fm, self.weight_im = weight_l2, weight_gan, weight_fm, weight_im
         self.renderer = ComputeDepthMaps(projection, 1.0, image_size)
-        self.criterion = torch.nn.MSELoss()
         self.rng = random.Random(seed)
 
     def _render_views(self, cloud, radius):
@@ -199,139 +179,25 @@ class GanStep:
         input_imgs = self._render_views(partial, radius)
         d_real = self.discriminator(torch.cat((input_imgs, real_imgs), dim=1).detach())
         d_fake = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1).detach())
-        err_d_real, err_d_fake = self.criterion(d_real, real_label), self.criterion(d_fake, fake_label)
+        err_d_real, err_d_fake = discriminator_objective(d_real, d_fake, real_label, fake_label)
         (err_d_real + err_d_fake).backward()
         self.opt_d.step()
 
         # ---- generator update: gradients reach the cloud through the renderer
         self.opt_g.zero_grad()
-        loss_fm = loss_im = 0.0
+        loss_fm = loss_im = None
         if self.use_fm:
             d_fake, fake_feats = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1), feat=True)
             _, real_feats = self.discriminator(torch.cat((input_imgs, real_imgs), dim=1), feat=True)
-            maps = [f.shape[1] for f in fake_feats]
-            for f, r, c in zip(fake_feats, real_feats, maps):
-                loss_fm = loss_fm + float(c) / sum(maps) * torch.mean((f - r.detach()) ** 2)
+            loss_fm = feature_matching(fake_feats, real_feats)
         else:
             d_fake = self.discriminator(torch.cat((input_imgs, fake_imgs), dim=1))
-        err_g_d = self.criterion(d_fake, real_label)
         if self.use_im:
             loss_im = torch.nn.functional.l1_loss(fake_imgs, real_imgs.detach())
-        err_g = self.weight_l2 * rec_loss + self.weight_gan * err_g_d
-        if self.use_fm:
-            err_g = err_g + self.weight_fm * loss_fm
-        if self.use_im:
-            err_g = err_g + self.weight_im * loss_im
+        err_g, err_g_d = generator_objective(rec_loss, d_fake, real_label, loss_fm, loss_im, self.weight_l2,
+                                             self.weight_gan, self.weight_fm, self.weight_im)
         err_g.backward()
         self.opt_g.step()
         return dict(rec_loss=rec_loss.detach(), errG=err_g.detach(), errG_D=err_g_d.detach(),
                     errD_real=err_d_real.detach(), errD_fake=err_d_fake.detach(),
                     coarse_loss=coarse_loss.detach() * 1000, refine_loss=refine_loss.detach() * 1000)
-
-
-class EdgeConvEncoder(torch.nn.Module):
-    """The encoder's data flow (EdgeConvResFeat, models/sparenet_generator.py:122-260) with the tensor shapes the
-    ops see: four EdgeConv stages on the 3000-point partial cloud -- k-NN graph in FEATURE space (C = 3, h/16,
-    h/16, h/8 channels, k = 8), edge features [B, 2C, N, k], a 1x1 convolution, max over the neighbours, a
-    residual 1x1 branch -- then a 1x1 convolution on the concatenated stages and global max + mean pooling.
-    Convolutions / norms run under bf16 autocast, the graph ops (sn_knn, sn_graph_feature_*) in fp32."""
-
-    def __init__(self, hide_size=4096, output_size=4096, k=8):
-        super().__init__()
-        h = hide_size
-        self.k = k
-        dims = [(6, h // 16), (h // 8, h // 16), (h // 8, h // 8), (h // 4, h // 4)]
-        self.edge = torch.nn.ModuleList(torch.nn.Conv2d(i, o, 1, bias=False) for i, o in dims)
-        self.norm = torch.nn.ModuleList(torch.nn.BatchNorm2d(o) for _, o in dims)
-        self.res = torch.nn.ModuleList([torch.nn.Conv1d(h // 16, h // 16, 1, bias=False),
-                                        torch.nn.Conv1d(h // 16, h // 8, 1, bias=False),
-                                        torch.nn.Conv1d(h // 8, h // 4, 1, bias=False)])
-        self.head = torch.nn.Conv1d(h // 2, output_size // 2, 1, bias=False)
-        self.head_norm = torch.nn.BatchNorm1d(output_size // 2)
-
-    def forward(self, x):                                   # [B, 3, N]
-        feats, cur = [], x
-        for i in range(4):
-            edges = get_graph_feature(cur.float(), k=self.k)               # fp32 HIP ops: [B, 2C, N, k]
-            with torch.autocast(x.device.type, dtype=torch.bfloat16):
-                y = torch.nn.functional.leaky_relu(self.norm[i](self.edge[i](edges)), 0.2).amax(dim=-1)
-                if i > 0:
-                    y = y + self.res[i - 1](cur)
-            cur = y
-            feats.append(y)
-        with torch.autocast(x.device.type, dtype=torch.bfloat16):
-            z = torch.nn.functional.leaky_relu(self.head_norm(self.head(torch.cat(feats, dim=1))), 0.2)
-            return torch.cat((z.amax(dim=2), z.mean(dim=2)), dim=1).float()   # [B, output_size]
-
-
-class FoldingDecoder(torch.nn.Module):
-    """A minimal stand-in for the style-based folding decoder: n_primitives 2-D grids + the global feature ->
-    [B, num_points, 3] through shared 1x1 convolutions (bf16 autocast)."""
-
-    def __init__(self, feature_size=4096, num_points=16384, n_primitives=32, width=256):
-        super().__init__()
-        self.num_points, self.n_primitives = num_points, n_primitives
-        self.proj = torch.nn.Linear(feature_size, width)
-        self.prim = torch.nn.Parameter(torch.randn(n_primitives, width) * 0.1)
-        self.net = torch.nn.Sequential(torch.nn.Conv1d(2 + width, width, 1), torch.nn.ReLU(),
-                                       torch.nn.Conv1d(width, width // 2, 1), torch.nn.ReLU(),
-                                       torch.nn.Conv1d(width // 2, 3, 1), torch.nn.Tanh())
-        per = num_points // n_primitives
-        side = int(per ** 0.5)
-        u = torch.linspace(-1, 1, side)
-        grid = torch.stack(torch.meshgrid(u, u, indexing="ij"), 0).reshape(2, -1)
-        grid = torch.nn.functional.pad(grid, (0, per - grid.shape[1]))
-        self.register_buffer("grid", grid.repeat(1, n_primitives), persistent=False)       # [2, N]
-
-    def forward(self, feature):                              # [B, F]
-        b = feature.shape[0]
-        with torch.autocast(feature.device.type, dtype=torch.bfloat16):
-            code = self.proj(feature).unsqueeze(1) + self.prim.unsqueeze(0)                # [B, P, W]
-            code = code.repeat_interleave(self.num_points // self.n_primitives, dim=1).transpose(1, 2)
-            pts = self.net(torch.cat((self.grid.unsqueeze(0).expand(b, -1, -1), code), dim=1))
-        return (0.5 * pts.float()).transpose(1, 2).contiguous()                            # [B, N, 3]
-
-
-class NetworkGenerator(torch.nn.Module):
-    """partial -> EdgeConv encoder -> folding decoder -> coarse; then the two refine stages of
-    SurrogateGenerator (expansion -> MDS -> gather) with a small residual 1x1 network each."""
-
-    def __init__(self, num_points=16384, n_primitives=32, hide_size=4096, feature_size=4096):
-        super().__init__()
-        self.encoder = EdgeConvEncoder(hide_size, feature_size)
-        self.decoder = FoldingDecoder(feature_size, num_points, n_primitives)
-        self.refine1 = ResidualRefine(num_points, n_primitives)
-        self.refine2 = ResidualRefine(num_points, n_primitives)
-
-    def forward(self, partial):                              # [B, M, 3]
-        part = partial.transpose(1, 2).contiguous()
-        coarse = self.decoder(self.encoder(part))
-        middle, loss_mst = self.refine1(coarse.transpose(1, 2).contiguous(), part, coarse)
-        refine, _ = self.refine2(middle.transpose(1, 2).contiguous(), part, middle)
-        return coarse, middle, refine, loss_mst
-
-
-class ResidualRefine(SurrogateRefine):
-    """SurrogateRefine with the offset field replaced by a small 1x1 residual network on the [B, 4, N] cloud."""
-
-    def __init__(self, num_points, n_primitives=32, width=64):
-        torch.nn.Module.__init__(self)
-        self.num_points, self.n_primitives = num_points, n_primitives
-        self.expansion = expansionPenaltyModule()
-        self.net = torch.nn.Sequential(torch.nn.Conv1d(4, width, 1), torch.nn.ReLU(),
-                                       torch.nn.Conv1d(width, width, 1), torch.nn.ReLU(),
-                                       torch.nn.Conv1d(width, 3, 1), torch.nn.Tanh())
-
-    def forward(self, inps, partial, coarse):
-        dist, _, mean_mst_dis = self.expansion(coarse, self.num_points // self.n_primitives, 1.5)
-        loss_mst = torch.mean(dist)
-        id0 = torch.zeros(inps.shape[0], 1, inps.shape[2], device=inps.device)
-        id1 = torch.ones(partial.shape[0], 1, partial.shape[2], device=partial.device)
-        base = torch.cat((torch.cat((inps, id0), 1), torch.cat((partial, id1), 1)), 2)   # [B,4,N+M]
-        idx = MDS_module.minimum_density_sample(base[:, 0:3, :].transpose(1, 2).contiguous(),
-                                                coarse.shape[1], mean_mst_dis)
-        base = MDS_module.gather_operation(base.contiguous(), idx)
-        with torch.autocast(base.device.type, dtype=torch.bfloat16):
-            delta = self.net(base)
-        outs = base[:, 0:3, :] + 0.05 * delta.float()
-        return outs.transpose(2, 1).contiguous(), loss_mst

@@ -1,0 +1,207 @@
+"""the learned networks (sparenet_amd/networks.py) and the step's loss arithmetic.
+
+CPU: every network block against golden outputs of the REFERENCE's own classes (imported on the CPU by
+tests/golden/gen_networks.py, parameters re-keyed to this layout) -- in particular the batched 32-primitive
+style decoder against the reference's per-primitive loop; the loss / GAN objectives against a numpy
+restatement of runners/sparenet_runner.py:83-108 and runners/sparenet_gan_runner.py:243-347 on known tensors;
+gradient equality of the DistributedDataParallel wrapper (gloo, world size 2) with the single-process run.
+GPU: the whole generator (HIP ops inside) steps and trains."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sparenet_amd import networks as nw
+
+
+def _load(module, z):
+    sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p:")}
+    own = module.state_dict()
+    for k, v in sd.items():
+        assert k in own, k
+        assert own[k].shape == v.shape, (k, own[k].shape, v.shape)
+    missing = [k for k in own if k not in sd and "num_batches_tracked" not in k and "grid" not in k]
+    assert not missing, missing
+    module.load_state_dict(sd, strict=False)
+    return module.train()
+
+
+@pytest.mark.parametrize("name", ["networks_encoder", "networks_encoder_se"])
+def test_encoder_matches_reference_classes(name, golden_dir):
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    enc = _load(nw.EdgeConvEncoder(int(z["hide"]), int(z["out"]), int(z["bott"]), use_se=bool(z["use_se"])), z)
+    y = enc(torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=2e-4, atol=2e-5)
+
+
+def test_batched_style_decoder_matches_reference_primitive_loop(golden_dir):
+    z = np.load(os.path.join(golden_dir, "networks_decoder.npz"))
+    P, n = int(z["P"]), int(z["n"])
+    dec = _load(nw.StyleFoldingDecoder(P * n, P, int(z["style_dim"]), int(z["width"])), z)
+    y = dec(torch.from_numpy(z["style"]))
+    assert y.shape == z["y"].shape
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=2e-4, atol=2e-5)
+
+
+def test_residual_network_matches_reference_class(golden_dir):
+    z = np.load(os.path.join(golden_dir, "networks_residual.npz"))
+    net = _load(nw.PointNetResidual(False), z)
+    y = net(torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(y.detach().numpy(), z["y"], rtol=2e-4, atol=2e-5)
+
+
+def test_squeeze_excite_and_lattice():
+    x = torch.rand(2, 32, 7)
+    se = nw.SqueezeExcite(32)
+    w1, w2 = se.fc[0].weight, se.fc[2].weight
+    gate = torch.sigmoid(torch.relu(x.mean(2) @ w1.t()) @ w2.t())
+    assert torch.allclose(se(x), x * gate.unsqueeze(-1))
+    g = nw.folding_grid(512)                       # 16 x 32 lattice in [-1, 1]^2, row-major (i outer)
+    assert g.shape == (2, 512) and float(g.min()) == -1.0 and float(g.max()) == 1.0
+    assert torch.allclose(g[:, 1] - g[:, 0], torch.tensor([0.0, 2.0 / 31]))
+    assert torch.allclose(g[:, 32] - g[:, 0], torch.tensor([2.0 / 15, 0.0]))
+
+
+def test_parameter_counts_equal_the_reference_modules():
+    cnt = lambda m: sum(p.numel() for p in m.parameters())
+    dec = nw.StyleFoldingDecoder()
+    assert cnt(nw.EdgeConvEncoder()) == 23_156_224
+    assert cnt(dec.mlp) == 31_489_542 and (cnt(dec) - cnt(dec.mlp)) == 32 * 665_874
+    assert cnt(nw.PointNetResidual()) == 867_145 - 6          # the reference's unused BatchNorm1d(3)
+    assert cnt(nw.PatchDiscriminator()) == 2_818_977 - 13_809  # its power-iteration vectors are buffers here
+
+
+# ------------------------------------------------------------------ loss arithmetic, closed form
+def test_completion_loss_closed_form():
+    rng = np.random.default_rng(0)
+    emd = [rng.random((3, 64), dtype=np.float32) for _ in range(3)]       # dist tensors of the three clouds
+    pen = rng.random((3, 64), dtype=np.float32)
+    d1 = rng.random((3, 64), dtype=np.float32)
+    t = [nw.emd_term(torch.from_numpy(e)) for e in emd]
+    got = nw.completion_loss(t[0], t[1], t[2], torch.from_numpy(pen), torch.from_numpy(d1))
+    want = sum(np.sqrt(e.astype(np.float64)).mean(1).mean() for e in emd) + 0.1 * pen.mean(dtype=np.float64) \
+        + 0.5 * d1.mean(dtype=np.float64)
+    np.testing.assert_allclose(float(got), want, rtol=1e-6)
+    got2 = nw.completion_loss(t[0], t[1], t[2], torch.from_numpy(pen))     # use_consist_loss = False
+    np.testing.assert_allclose(float(got2), want - 0.5 * d1.mean(dtype=np.float64), rtol=1e-6)
+
+
+def test_gan_objectives_closed_form():
+    rng = np.random.default_rng(1)
+    B = 4
+    d_fake, d_real = rng.random((B, 1), dtype=np.float32), rng.random((B, 1), dtype=np.float32)
+    feats_f = [rng.random((B, c, 5, 5), dtype=np.float32) for c in (16, 32, 64, 128)]
+    feats_r = [rng.random((B, c, 5, 5), dtype=np.float32) for c in (16, 32, 64, 128)]
+    fake, real = rng.random((B, 8, 6, 6), dtype=np.float32), rng.random((B, 8, 6, 6), dtype=np.float32)
+    rec = np.float32(0.0123)
+    ones, zeros = np.ones((B, 1), np.float32), np.zeros((B, 1), np.float32)
+    T = torch.from_numpy
+    fm = nw.feature_matching([T(f) for f in feats_f], [T(r) for r in feats_r])
+    fm_np = sum(c / 240.0 * ((f.astype(np.float64) - r) ** 2).mean()
+                for c, f, r in zip((16, 32, 64, 128), feats_f, feats_r))
+    np.testing.assert_allclose(float(fm), fm_np, rtol=1e-6)
+    im = torch.nn.functional.l1_loss(T(fake), T(real))
+    err_g, err_g_d = nw.generator_objective(T(np.array(rec)), T(d_fake), T(ones), fm, im)
+    gd = ((d_fake.astype(np.float64) - 1) ** 2).mean()
+    want = 200.0 * rec + 0.1 * gd + 1.0 * fm_np + 1.0 * np.abs(fake.astype(np.float64) - real).mean()
+    np.testing.assert_allclose(float(err_g_d), gd, rtol=1e-6)
+    np.testing.assert_allclose(float(err_g), want, rtol=1e-6)
+    e_r, e_f = nw.discriminator_objective(T(d_real), T(d_fake), T(ones), T(zeros))
+    np.testing.assert_allclose(float(e_r), ((d_real.astype(np.float64) - 1) ** 2).mean(), rtol=1e-6)
+    np.testing.assert_allclose(float(e_f), (d_fake.astype(np.float64) ** 2).mean(), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ data parallel wrapper, gloo world 2
+def _tiny_generator():
+    torch.manual_seed(11)
+    return nw.Generator(num_points=128, n_primitives=4, hide_size=64, bottleneck_size=32, width=18, refine=False)
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gen = _tiny_generator().eval()                     # running statistics: samples independent of their batch
+    ddp = nw.data_parallel(gen, None, bucket_cap_mb=1)
+    g = torch.Generator().manual_seed(5)
+    partial = torch.rand(4, 30, 3, generator=g) - 0.5
+    lo, hi = rank * 2, rank * 2 + 2
+    coarse, _, _, _ = ddp(partial[lo:hi])
+    coarse.pow(2).mean().backward()                    # DDP averages the two ranks' gradients
+    flat = torch.cat([p.grad.reshape(-1) for p in gen.parameters()])
+    np.save(os.path.join(out_dir, f"g{rank}.npy"), flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_equal_single_process(tmp_path):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npy"), np.load(tmp_path / "g1.npy")
+    assert np.array_equal(g0, g1)
+    gen = _tiny_generator().eval()
+    g = torch.Generator().manual_seed(5)
+    partial = torch.rand(4, 30, 3, generator=g) - 0.5
+    coarse, _, _, _ = gen(partial)
+    coarse.pow(2).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in gen.parameters()]).numpy()
+    np.testing.assert_allclose(g0, ref, rtol=1e-4, atol=1e-7)
+
+
+# ------------------------------------------------------------------ GPU: the whole step
+@pytest.mark.gpu
+def test_generator_step_with_hip_ops_trains(dev):
+    """Generator (EdgeConv encoder on sn_knn / sn_graph_feature, batched style decoder, two refine passes
+    through sn_expansion / sn_mds / sn_gather) + completion() with the EMD metric: finite gradients on every
+    parameter, Adam reduces the loss."""
+    from sparenet_amd.harness import Completion
+
+    torch.manual_seed(0)
+    B, N, M = 4, 2048, 512
+    gen = nw.Generator(num_points=N, n_primitives=4, hide_size=256, bottleneck_size=128, width=66).to(dev)
+    comp = Completion("emd", use_consist_loss=True, overlap=False).to(dev)
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(B, N, 3, generator=g)
+    gt = (0.4 * v / v.norm(dim=2, keepdim=True)).to(dev)
+    partial = (gt[:, :M] + 1e-3 * torch.randn(B, M, 3, generator=g).to(dev)).contiguous()
+    opt = torch.optim.Adam(gen.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(6):
+        loss, refine, middle, coarse, _, _ = comp(gen, partial, gt)
+        assert refine.shape == middle.shape == coarse.shape == (B, N, 3)
+        opt.zero_grad()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gen.parameters())
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_gan_step_with_reference_networks(dev):
+    """The GAN step (sparenet_gan_runner.py:69-347) with the PatchDiscriminator and the Generator: both
+    optimisers move their parameters, the objectives are finite."""
+    from sparenet_amd.harness import Completion, GanStep
+
+    torch.manual_seed(1)
+    B, N, M, S = 2, 2048, 512, 64
+    gen = nw.Generator(num_points=N, n_primitives=4, hide_size=256, bottleneck_size=128, width=66).to(dev)
+    disc = nw.PatchDiscriminator((16, S, S)).to(dev)
+    g = torch.Generator().manual_seed(3)
+    v = torch.randn(B, N, 3, generator=g)
+    gt = (0.4 * v / v.norm(dim=2, keepdim=True)).to(dev)
+    partial = (gt[:, :M] + 1e-3 * torch.randn(B, M, 3, generator=g).to(dev)).contiguous()
+    step = GanStep(gen, disc, Completion("chamfer", overlap=False).to(dev), torch.optim.Adam(gen.parameters(), 1e-4),
+                   torch.optim.Adam(disc.parameters(), 1e-4), radius_list=[2.0, 3.0], image_size=S)
+    before_g = [p.detach().clone() for p in gen.parameters()]
+    before_d = [p.detach().clone() for p in disc.parameters()]
+    out = step(partial, gt)
+    assert all(torch.isfinite(out[k]).all() for k in ("rec_loss", "errG", "errG_D", "errD_real", "errD_fake"))
+    assert any(not torch.equal(a, b) for a, b in zip(before_g, gen.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(before_d, disc.parameters()))
