@@ -16,6 +16,10 @@
  *   3. leaf stripping (:120-147) with SNAPSHOT semantics: all cnt[] reads of a
  *      round precede its decrements.  (On the GPU the reads are live and the
  *      owner of the last star's final edge is timing dependent; see DESIGN.md.)
+ *      Observed: the reference kernel text run under tests/golden/gen/simt.h with randomised thread
+ *      schedules changes dist / assignment on tests/golden/xfail_expansion_rand_3x64_P16.npz (one edge's
+ *      owner flips between its two endpoints); the multiset of penalised lengths and the mean MST
+ *      length do not change -- those are what the loss uses.
  */
 #include "sn_oracle.h"
 #include <math.h>

@@ -7,7 +7,15 @@
 // not a build of the reference: scheduling-dependent behaviour (races the
 // kernels formally contain) is resolved by whatever the host threads do, so the
 // generator screens fixtures for such events (see gen_emulated.py).
+//
+// Schedule knob: SIMT_SCHED_SEED=<n> (n > 0) in the environment starts the threads of every block in a
+// random order and injects sched_yield() at barriers and atomics with probability 1/8 per thread and event
+// (a per-thread LCG seeded from n).  gen_emulated.py runs every fixture under several seeds and only calls
+// a fixture schedule invariant if all runs agree byte for byte.
 #pragma once
+#include <sched.h>
+
+#include <random>
 #include <algorithm>
 #include <barrier>
 #include <cmath>
@@ -26,6 +34,13 @@ struct dim3 {
 static thread_local dim3 threadIdx;
 static dim3 blockIdx, blockDim, gridDim;
 static std::barrier<> *g_barrier = nullptr;
+static const unsigned g_sched_seed = getenv("SIMT_SCHED_SEED") ? (unsigned)atoi(getenv("SIMT_SCHED_SEED")) : 0u;
+static thread_local uint64_t t_sched_rng = 0;
+static inline void simt_perturb() {
+  if (!g_sched_seed) return;
+  t_sched_rng = t_sched_rng * 6364136223846793005ULL + 1442695040888963407ULL;
+  if (((t_sched_rng >> 33) & 7u) == 0u) sched_yield();
+}
 
 #define __global__
 #define __device__
@@ -33,15 +48,27 @@ static std::barrier<> *g_barrier = nullptr;
 #define __forceinline__ inline
 #define __restrict__
 #define __shared__ static
-static inline void __syncthreads() { g_barrier->arrive_and_wait(); }
+static inline void __syncthreads() {
+  simt_perturb();
+  g_barrier->arrive_and_wait();
+  simt_perturb();
+}
 
-static inline int atomicAdd(int *p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicAdd(int *p, int v) {
+  simt_perturb();
+  return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST);
+}
 static inline int atomicCAS(int *p, int cmp, int v) {
+  simt_perturb();
   __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
   return cmp;
 }
-static inline int atomicExch(int *p, int v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
+static inline int atomicExch(int *p, int v) {
+  simt_perturb();
+  return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST);
+}
 static inline float atomicAdd(float *p, float v) {
+  simt_perturb();
   int *ip = reinterpret_cast<int *>(p);
   int old = __atomic_load_n(ip, __ATOMIC_SEQ_CST);
   for (;;) {
@@ -82,11 +109,20 @@ static void simt_launch(K kernel, dim3 grid, dim3 block, Args... args) {
         g_barrier = &bar;
         std::vector<std::thread> ts;
         ts.reserve(nthreads);
-        for (unsigned t = 0; t < nthreads; ++t)
+        std::vector<unsigned> order(nthreads);
+        for (unsigned t = 0; t < nthreads; ++t) order[t] = t;
+        if (g_sched_seed) {
+          std::mt19937 rng(g_sched_seed * 7919u + bx + 131u * by + 17161u * bz);
+          std::shuffle(order.begin(), order.end(), rng);
+        }
+        for (unsigned k = 0; k < nthreads; ++k) {
+          const unsigned t = order[k];
           ts.emplace_back([=]() {
             threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+            t_sched_rng = ((uint64_t)g_sched_seed << 32) ^ (0x9E3779B97F4A7C15ULL * (t + 1));
             kernel(args...);
           });
+        }
         for (auto &th : ts) th.join();
       }
 }

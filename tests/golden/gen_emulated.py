@@ -12,9 +12,11 @@ inputs and stores inputs + outputs as .npz.
 What this pins: arithmetic, tie rules and control flow of the kernel text under
 sequentially consistent thread execution.  What it does not pin: the outcome of
 the kernels' own data races on real GPU hardware (EMD GetMax near-ties,
-expansion leaf-stripping of the last star, MDS) -- fixtures where the emulated
-run disagrees with the oracle's documented canonical rule are reported, not
-stored.
+expansion leaf-stripping of the last star, MDS) -- every fixture is run under several
+thread schedules (random start order + yields, SIMT_SCHED_SEED in simt.h); a
+fixture that differs between schedules or from the oracle's documented canonical
+rule is NOT dropped: it is stored as xfail_<name>.npz with the reason, and the
+tests report it as an expected failure.
 
 Usage: python tests/golden/gen_emulated.py [emd] [expansion] ...
 """
@@ -55,15 +57,50 @@ def compile_harness(src, inc, exe):
     return exe
 
 
-def run(exe, header, arrays):
+SCHED_SEEDS = [int(v) for v in os.environ.get("GEN_SCHED_SEEDS", "1,2,3,4,5").split(",") if v]
+
+
+def run(exe, header, arrays, sched_seed=0):
     fin = os.path.join(TMP, "in.bin")
     fout = os.path.join(TMP, "out.bin")
     with open(fin, "wb") as f:
         f.write(header)
         for a in arrays:
             f.write(np.ascontiguousarray(a).tobytes())
-    subprocess.check_call([exe, fin, fout])
+    env = dict(os.environ)
+    env.pop("SIMT_SCHED_SEED", None)
+    if sched_seed:
+        env["SIMT_SCHED_SEED"] = str(sched_seed)
+    subprocess.check_call([exe, fin, fout], env=env)
     return open(fout, "rb").read()
+
+
+def run_schedules(exe, header, arrays, fields, seeds=None):
+    """The canonical run (threads started in order, no yields) plus one run per schedule seed
+    (tests/golden/gen/simt.h: random start order, sched_yield at barriers / atomics).  `fields` = [(name,
+    byte offset, byte length)].  Returns (canonical bytes, {field: schedules in which it differs})."""
+    base = run(exe, header, arrays)
+    varying = {}
+    for sd in (SCHED_SEEDS if seeds is None else seeds):
+        raw = run(exe, header, arrays, sd)
+        for name, off, ln in fields:
+            if raw[off:off + ln] != base[off:off + ln]:
+                varying.setdefault(name, []).append(sd)
+    return base, varying
+
+
+def store(name, agree, varying, reason, **arrays):
+    """Fixtures are never dropped: one that disagrees with the oracle's canonical rule, or that differs between
+    schedules, is stored as xfail_<name>.npz with the reason (tests report it as an expected failure)."""
+    ok = agree and not varying
+    path = os.path.join(HERE, ("" if ok else "xfail_") + name + ".npz")
+    other = os.path.join(HERE, ("xfail_" if ok else "") + name + ".npz")
+    if os.path.exists(other):
+        os.remove(other)
+    extra = {} if ok else {"reason": np.array(reason + (f"; schedule dependent fields {varying}" if varying else ""))}
+    np.savez_compressed(path, schedules_checked=np.int32(len(SCHED_SEEDS)),
+                        schedule_invariant=np.bool_(not varying), **extra, **arrays)
+    return ok
 
 
 # ------------------------------------------------------------------------ EMD
@@ -99,7 +136,11 @@ def gen_emd():
         x, y = x.numpy(), y.numpy()
         if os.environ.get("GEN_ONLY") and os.environ["GEN_ONLY"] not in name:
             continue
-        raw = run(exe, struct.pack("iiif", b, n, iters, eps), [x, y])
+        fields = [("dist", 0, 4 * b * n), ("assignment", 4 * b * n, 4 * b * n), ("price", 8 * b * n, 4 * b * n),
+                  ("unass", 12 * b * n, 4 * iters)]
+        raw, varying = run_schedules(exe, struct.pack("iiif", b, n, iters, eps), [x, y], fields,
+                                     SCHED_SEEDS[:2] if iters * n > 40000 else None)
+        varying.pop("price", None)   # the forced last-iteration price update races by design (emd_cuda.cu:207-215)
         o = 0
         dist = np.frombuffer(raw, np.float32, b * n, o).reshape(b, n); o += 4 * b * n
         assign = np.frombuffer(raw, np.int32, b * n, o).reshape(b, n); o += 4 * b * n
@@ -108,14 +149,11 @@ def gen_emd():
         od, oa, aux = oracle.emd_forward(x, y, eps, iters, return_aux=True)
         agree = np.array_equal(oa, assign) and np.array_equal(od, dist) and \
             np.array_equal(aux["unass"], trace)
-        print(f"{name}: emulated vs oracle agree={agree} unass={trace[:8]}...")
-        if not agree:
-            print("   NOT stored (race outcome or oracle bug) -- investigate")
-            continue
-        np.savez_compressed(
-            os.path.join(HERE, name + ".npz"), xyz1=x, xyz2=y, eps=np.float32(eps),
-            iters=np.int32(iters), dist=dist, assignment=assign, unass=trace,
-            provenance=np.array("reference emd_cuda.cu:10-226 kernel text under tests/golden/gen/simt.h"))
+        print(f"{name}: emulated vs oracle agree={agree} schedule-dependent fields={varying or None} unass={trace[:8]}...")
+        store(name, agree, varying, "emulated reference kernels disagree with the oracle's canonical rule "
+              "(GetMax near-tie race outcome, emd_cuda.cu:181-194, or an oracle bug)",
+              xyz1=x, xyz2=y, eps=np.float32(eps), iters=np.int32(iters), dist=dist, assignment=assign, unass=trace,
+              provenance=np.array("reference emd_cuda.cu:10-226 kernel text under tests/golden/gen/simt.h"))
 
 
 # ------------------------------------------------------------------ expansion
@@ -137,7 +175,8 @@ def gen_expansion():
             x = (torch.randint(0, 5, (b, n, 3), generator=g).float() / 4).numpy()
         else:
             x = torch.rand(b, n, 3, generator=g).numpy()
-        raw = run(exe, struct.pack("iiif", b, n, P, alpha), [x])
+        fields = [("dist", 0, 4 * b * n), ("assignment", 4 * b * n, 4 * b * n), ("mean_mst_sum", 8 * b * n, 4 * b)]
+        raw, varying = run_schedules(exe, struct.pack("iiif", b, n, P, alpha), [x], fields)
         o = 0
         dist = np.frombuffer(raw, np.float32, b * n, o).reshape(b, n); o += 4 * b * n
         assign = np.frombuffer(raw, np.int32, b * n, o).reshape(b, n); o += 4 * b * n
@@ -146,14 +185,13 @@ def gen_expansion():
         agree = np.array_equal(od, dist) and np.array_equal(oa, assign) and np.array_equal(om, mean)
         same_set = np.array_equal(np.sort(od, 1), np.sort(dist, 1)) and np.array_equal(om, mean)
         print(f"{name}: emulated vs oracle agree={agree} (race-invariant part agrees={same_set}) "
-              f"penalised={int((assign >= 0).sum())}")
-        if not agree:
-            print("   NOT stored -- leaf-stripping race materialised in the emulated run or bug")
-            continue
-        np.savez_compressed(
-            os.path.join(HERE, name + ".npz"), xyz=x, primitive_size=np.int32(P),
-            alpha=np.float32(alpha), dist=dist, assignment=assign, mean_mst_sum=mean,
-            provenance=np.array("reference expansion_penalty_cuda.cu:7-149 kernel text under tests/golden/gen/simt.h"))
+              f"schedule-dependent fields={varying or None} penalised={int((assign >= 0).sum())}")
+        store(name, agree, varying, "leaf-stripping race of the last star (expansion_penalty_cuda.cu:126-135) "
+              "materialised in the emulated run: edge ownership differs from the oracle's snapshot rule; the "
+              "race-invariant part (sorted dist, mean) " + ("agrees" if same_set else "DISAGREES"),
+              xyz=x, primitive_size=np.int32(P), alpha=np.float32(alpha), dist=dist, assignment=assign,
+              mean_mst_sum=mean,
+              provenance=np.array("reference expansion_penalty_cuda.cu:7-149 kernel text under tests/golden/gen/simt.h"))
 
 
 # ------------------------------------------------------------------------ MDS

@@ -26,6 +26,25 @@ def test_oracle_matches_emulated_reference_golden(golden_dir):
         assert np.array_equal(m, z["mean_mst_sum"]), f
 
 
+def test_schedule_dependent_emulations_are_recorded_not_dropped(golden_dir):
+    """gen_emulated.py runs the reference kernel text under several thread schedules (simt.h).  A fixture in
+    which the leaf-stripping race of the last star (expansion_penalty_cuda.cu:126-135) materialises -- the
+    owner of one edge per affected patch depends on the schedule -- is kept as xfail_*.npz: the race-invariant
+    part (the multiset of penalised lengths, the mean MST length) must still equal the oracle's; the
+    per-endpoint ownership is reported as an expected failure with the stored reason."""
+    files = sorted(glob.glob(os.path.join(golden_dir, "xfail_expansion_*.npz")))
+    for f in files:
+        z = np.load(f)
+        d, a, m = oracle.expansion_forward(z["xyz"], int(z["primitive_size"]), float(z["alpha"]))
+        assert np.array_equal(np.sort(d, 1), np.sort(z["dist"], 1)), f
+        assert np.array_equal(m, z["mean_mst_sum"]), f
+    diverging = [f for f in files if not np.array_equal(
+        oracle.expansion_forward(np.load(f)["xyz"], int(np.load(f)["primitive_size"]), float(np.load(f)["alpha"]))[1],
+        np.load(f)["assignment"])]
+    if diverging:
+        pytest.xfail(str(np.load(diverging[0])["reason"]))
+
+
 def test_oracle_mst_weight_vs_scipy():
     from scipy.sparse.csgraph import minimum_spanning_tree
     from scipy.spatial.distance import cdist
