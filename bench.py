@@ -49,6 +49,10 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+if os.environ.get("AB_LIB"):   # A/B a saved build of the library (tools/build_variant.sh); never set by the driver
+    import sparenet_amd._lib as _ab
+    _ab.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
+
 from sparenet_amd.dist_utils import reduce_mean_of_means, shard  # noqa: E402
 
 B, N = 32, 16384

@@ -62,7 +62,9 @@ int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, int n,
                        int *idx2, void *stream);
 /* replaces cd.backward_cuda = chamfer_distance_backward_cuda
  *          (chamfer_distance.cpp:40-55,188; kernel chamfer_distance.cu:159-209)
- * gradxyz1/gradxyz2 are fully overwritten (no pre-zeroing needed). */
+ * gradxyz1/gradxyz2 are fully overwritten (no pre-zeroing needed).  The scatter of the reference is a
+ * gather over inverse lists built in `workspace` (integer atomics only): the result is bit-reproducible and
+ * bit-equal to the reference's CPU path, which adds the same terms in the same order. */
 /* Same result as sn_chamfer_forward (distances bit for bit, indices = lowest k attaining the
  * minimum), computed as a spatially pruned search: both clouds are Morton sorted into the
  * workspace, superblocks of 64 targets are skipped by bounding box, the surviving pairs are
@@ -73,10 +75,12 @@ int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, int b, int n
                               int m, float *dist1, int *idx1, float *dist2,
                               int *idx2, void *workspace, size_t workspace_bytes,
                               void *stream);
+size_t sn_chamfer_backward_workspace_bytes(int b, int n, int m);
 int sn_chamfer_backward(const float *xyz1, const float *xyz2,
                         const float *graddist1, const float *graddist2,
                         const int *idx1, const int *idx2, int b, int n, int m,
-                        float *gradxyz1, float *gradxyz2, void *stream);
+                        float *gradxyz1, float *gradxyz2, void *workspace,
+                        size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------- EMD
  * replaces emd.forward = emd_forward -> emd_cuda_forward

@@ -194,56 +194,165 @@ __global__ __launch_bounds__(kThreads) void chamfer_fwd_kernel(
 }
 
 // ---------------------------------------------------------------- backward
-// pass 1 (plain stores): own term  grad_a[j] = 2*gd[j] * (a[j] - b[idx[j]])
-__global__ __launch_bounds__(256) void chamfer_bwd_own_kernel(
-    const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    const float *__restrict__ gd1, const float *__restrict__ gd2, const int *__restrict__ idx1,
-    const int *__restrict__ idx2, int B, int N, int M, float *__restrict__ g1,
-    float *__restrict__ g2) {
+// The reference's CPU path (chamfer_distance.cpp:114-180) accumulates, per cloud, first over the queries of
+// cloud 1 in ascending order (own term into gradxyz1, scatter term into gradxyz2[idx1[j]]), then over the
+// queries of cloud 2 (own term into gradxyz2, scatter term into gradxyz1[idx2[k]]):
+//     gradxyz1[j] = ( own1_j - s_{k1} - s_{k2} ... )            k ascending over {k : idx2[k] == j}
+//     gradxyz2[k] = ( -t_{j1} - t_{j2} ... ) + own2_k           j ascending over {j : idx1[j] == k}
+// Its GPU path scatters with fp32 atomics -- the same terms in an arbitrary order, so the last bits depend on
+// timing.  Here the scatter is turned into a GATHER: the inverse lists (who points at me?) are built with
+// integer atomics (count -> scan -> fill; the fill order is arbitrary, so every list is sorted before it is
+// used) and each point then adds its terms in exactly the order above: no floating-point atomic, results
+// bit-reproducible and bit-equal to the reference's own CPU build.
+struct BwdLists {
+  int *cnt;    // [B, N + M]  how many points of the other cloud chose me (entries 0..N-1: cloud 1, then cloud 2)
+  int *off;    // [B, N + M]  list start
+  int *fill;   // [B, N + M]  next free slot while filling
+  int *list;   // [B, N + M]  the inverse lists: lists of cloud-1 points hold indices k of cloud 2 and vice versa
+};
+
+__global__ __launch_bounds__(256) void chamfer_bwd_count_kernel(const int *__restrict__ idx1,
+                                                               const int *__restrict__ idx2, int B, int N,
+                                                               int M, int *__restrict__ cnt) {
   const long total1 = (long)B * N, total = total1 + (long)B * M;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
+  const int NM = N + M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const bool second = e >= total1;
     const long f = second ? e - total1 : e;
-    const int na = second ? M : N, nb = second ? N : M;
-    const int b = (int)(f / na);
-    const float *a = second ? xyz2 : xyz1;
-    const float *o = second ? xyz1 : xyz2;
-    const int k = (second ? idx2 : idx1)[f];
-    const float g = (second ? gd2 : gd1)[f] * 2;
-    const float *pa = a + f * 3;
-    const float *po = o + ((long)b * nb + k) * 3;
-    float *ga = (second ? g2 : g1) + f * 3;
-    ga[0] = g * (pa[0] - po[0]);
-    ga[1] = g * (pa[1] - po[1]);
-    ga[2] = g * (pa[2] - po[2]);
+    const int b = (int)(f / (second ? M : N));
+    // a cloud-1 query j votes for cloud-2 point idx1[j] (slot N + idx1[j]); a cloud-2 query for slot idx2[k]
+    const int slot = second ? idx2[f] : N + idx1[f];
+    atomicAdd(&cnt[(long)b * NM + slot], 1);
   }
 }
 
-// pass 2 (fp32 atomics): scatter term  grad_b[idx[j]] -= 2*gd[j] * (a[j] - b[idx[j]])
-__global__ __launch_bounds__(256) void chamfer_bwd_scatter_kernel(
-    const float *__restrict__ xyz1, const float *__restrict__ xyz2,
-    const float *__restrict__ gd1, const float *__restrict__ gd2, const int *__restrict__ idx1,
-    const int *__restrict__ idx2, int B, int N, int M, float *__restrict__ g1,
-    float *__restrict__ g2) {
+// exclusive scan of the counts of one cloud (both sides in one sequence); also primes the fill cursors
+__global__ __launch_bounds__(1024) void chamfer_bwd_scan_kernel(int NM, const int *__restrict__ cnt,
+                                                               int *__restrict__ off, int *__restrict__ fill) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long o = (long)b * NM;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < NM; base += 1024) {
+    const int i = base + tid;
+    const int c = i < NM ? cnt[o + i] : 0;
+    int incl = c;
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if ((tid & 63) >= d) incl += v;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+    if (i < NM) {
+      off[o + i] = pre + incl - c;
+      fill[o + i] = pre + incl - c;
+    }
+    __syncthreads();
+    if (tid == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void chamfer_bwd_fill_kernel(const int *__restrict__ idx1,
+                                                              const int *__restrict__ idx2, int B, int N,
+                                                              int M, int *__restrict__ fill,
+                                                              int *__restrict__ list) {
   const long total1 = (long)B * N, total = total1 + (long)B * M;
-  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
-       e += (long)gridDim.x * blockDim.x) {
+  const int NM = N + M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const bool second = e >= total1;
+    const long f = second ? e - total1 : e;
+    const int na = second ? M : N;
+    const int b = (int)(f / na);
+    const int self = (int)(f - (long)b * na);
+    const int slot = second ? idx2[f] : N + idx1[f];
+    const int pos = atomicAdd(&fill[(long)b * NM + slot], 1);
+    list[(long)b * NM + pos] = self;
+  }
+}
+
+// in-place ascending sort of a short int array in global memory owned by the calling thread
+__device__ __forceinline__ void sort_ints(int *a, int n) {
+  if (n <= 16) {  // insertion sort
+    for (int i = 1; i < n; ++i) {
+      const int v = a[i];
+      int j = i - 1;
+      while (j >= 0 && a[j] > v) {
+        a[j + 1] = a[j];
+        --j;
+      }
+      a[j + 1] = v;
+    }
+    return;
+  }
+  // heap sort: O(n log n) also for the degenerate case of thousands of queries sharing one neighbour
+  auto sift = [&](int start, int end) {
+    int root = start;
+    for (;;) {
+      int child = 2 * root + 1;
+      if (child > end) break;
+      if (child + 1 <= end && a[child] < a[child + 1]) ++child;
+      if (a[root] >= a[child]) break;
+      const int t = a[root];
+      a[root] = a[child];
+      a[child] = t;
+      root = child;
+    }
+  };
+  for (int start = (n - 2) / 2; start >= 0; --start) sift(start, n - 1);
+  for (int end = n - 1; end > 0; --end) {
+    const int t = a[0];
+    a[0] = a[end];
+    a[end] = t;
+    sift(0, end - 1);
+  }
+}
+
+__global__ __launch_bounds__(256) void chamfer_bwd_gather_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, const float *__restrict__ gd1,
+    const float *__restrict__ gd2, const int *__restrict__ idx1, const int *__restrict__ idx2, int B, int N,
+    int M, const int *__restrict__ cnt, const int *__restrict__ off, int *__restrict__ list,
+    float *__restrict__ g1, float *__restrict__ g2) {
+#pragma clang fp contract(off)
+  const long total1 = (long)B * N, total = total1 + (long)B * M;
+  const int NM = N + M;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
     const bool second = e >= total1;
     const long f = second ? e - total1 : e;
     const int na = second ? M : N, nb = second ? N : M;
     const int b = (int)(f / na);
-    const float *a = second ? xyz2 : xyz1;
-    const float *o = second ? xyz1 : xyz2;
-    const int k = (second ? idx2 : idx1)[f];
-    const float g = (second ? gd2 : gd1)[f] * 2;
+    const int self = (int)(f - (long)b * na);
+    const float *a = second ? xyz2 : xyz1;   // my cloud
+    const float *o = second ? xyz1 : xyz2;   // the other cloud
+    const float *gda = second ? gd2 : gd1, *gdo = second ? gd1 : gd2;
     const float *pa = a + f * 3;
-    const long ob = ((long)b * nb + k) * 3;
-    const float *po = o + ob;
-    float *go = (second ? g1 : g2) + ob;
-    unsafeAtomicAdd(go + 0, -(g * (pa[0] - po[0])));
-    unsafeAtomicAdd(go + 1, -(g * (pa[1] - po[1])));
-    unsafeAtomicAdd(go + 2, -(g * (pa[2] - po[2])));
+    // own term: g (me - my neighbour)
+    const int k = (second ? idx2 : idx1)[f];
+    const float *po = o + ((long)b * nb + k) * 3;
+    const float g = gda[f] * 2;
+    const float own[3] = {g * (pa[0] - po[0]), g * (pa[1] - po[1]), g * (pa[2] - po[2])};
+    const long slot = (long)b * NM + (second ? N : 0) + self;
+    const int c = cnt[slot];
+    int *lst = list + (long)b * NM + off[slot];
+    if (c > 1) sort_ints(lst, c);
+    // cloud 1: own term first, then the scatter terms; cloud 2: scatter terms first, own term last
+    float acc[3] = {second ? 0.f : own[0], second ? 0.f : own[1], second ? 0.f : own[2]};
+    for (int i = 0; i < c; ++i) {
+      const long q = (long)b * nb + lst[i];            // a point of the other cloud whose neighbour I am
+      const float *pq = o + q * 3;
+      const float gq = gdo[q] * 2;
+      acc[0] -= gq * (pq[0] - pa[0]);
+      acc[1] -= gq * (pq[1] - pa[1]);
+      acc[2] -= gq * (pq[2] - pa[2]);
+    }
+    float *out = (second ? g2 : g1) + f * 3;
+    out[0] = second ? acc[0] + own[0] : acc[0];
+    out[1] = second ? acc[1] + own[1] : acc[1];
+    out[2] = second ? acc[2] + own[2] : acc[2];
   }
 }
 
@@ -265,20 +374,38 @@ extern "C" int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, i
   return sn::launch_status("sn_chamfer_forward");
 }
 
+extern "C" size_t sn_chamfer_backward_workspace_bytes(int b, int n, int m) {
+  if (b < 1 || n < 1 || m < 1) return 0;
+  return 4 * sn::align_up((size_t)b * ((size_t)n + m) * 4, 256);
+}
+
 extern "C" int sn_chamfer_backward(const float *xyz1, const float *xyz2, const float *graddist1,
                                    const float *graddist2, const int *idx1, const int *idx2,
                                    int b, int n, int m, float *gradxyz1, float *gradxyz2,
-                                   void *stream) {
-  SN_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2,
+                                   void *workspace, size_t workspace_bytes, void *stream) {
+  SN_REQUIRE(xyz1 && xyz2 && graddist1 && graddist2 && idx1 && idx2 && gradxyz1 && gradxyz2 && workspace,
              "sn_chamfer_backward: null pointer");
   SN_REQUIRE(b >= 1 && n >= 1 && m >= 1, "sn_chamfer_backward: need b,n,m >= 1");
+  SN_REQUIRE((long)b * ((long)n + m) < (1L << 30), "sn_chamfer_backward: too large");
+  SN_REQUIRE(workspace_bytes >= sn_chamfer_backward_workspace_bytes(b, n, m),
+             "sn_chamfer_backward: workspace too small (%zu < %zu)", workspace_bytes,
+             sn_chamfer_backward_workspace_bytes(b, n, m));
+  const size_t arr = sn::align_up((size_t)b * ((size_t)n + m) * 4, 256);
+  char *p = static_cast<char *>(workspace);
+  BwdLists L;
+  L.cnt = reinterpret_cast<int *>(p);
+  L.off = reinterpret_cast<int *>(p + arr);
+  L.fill = reinterpret_cast<int *>(p + 2 * arr);
+  L.list = reinterpret_cast<int *>(p + 3 * arr);
   const long total = (long)b * n + (long)b * m;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = sn::as_stream(stream);
-  chamfer_bwd_own_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1, idx2,
-                                                      b, n, m, gradxyz1, gradxyz2);
-  chamfer_bwd_scatter_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1,
-                                                          idx2, b, n, m, gradxyz1, gradxyz2);
+  SN_HIP(hipMemsetAsync(L.cnt, 0, (size_t)b * ((size_t)n + m) * 4, s));
+  chamfer_bwd_count_kernel<<<(int)blocks, 256, 0, s>>>(idx1, idx2, b, n, m, L.cnt);
+  chamfer_bwd_scan_kernel<<<b, 1024, 0, s>>>(n + m, L.cnt, L.off, L.fill);
+  chamfer_bwd_fill_kernel<<<(int)blocks, 256, 0, s>>>(idx1, idx2, b, n, m, L.fill, L.list);
+  chamfer_bwd_gather_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1, idx2, b, n, m,
+                                                        L.cnt, L.off, L.list, gradxyz1, gradxyz2);
   return sn::launch_status("sn_chamfer_backward");
 }

@@ -6,6 +6,8 @@ backed by sn_chamfer_forward / sn_chamfer_backward (include/sparenet_hip.h).
 Difference: GPU tensors only -- a CPU tensor raises instead of taking the
 reference's single-threaded CPU branch (:31-32, :53-54).
 """
+import ctypes
+
 import torch
 
 from sparenet_amd import _lib
@@ -52,12 +54,14 @@ class _CdBinding:
         b, n, _ = xyz1.shape
         m = xyz2.shape[1]
         with torch.cuda.device_of(xyz1):
+            nbytes = _lib.lib().sn_chamfer_backward_workspace_bytes(b, n, m)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=xyz1.device)   # inverse neighbour lists
             code = _lib.lib().sn_chamfer_backward(
                 _lib.fptr(xyz1, "xyz1"), _lib.fptr(xyz2, "xyz2"),
                 _lib.fptr(graddist1, "graddist1"), _lib.fptr(graddist2, "graddist2"),
                 _lib.iptr(idx1, "idx1"), _lib.iptr(idx2, "idx2"), b, n, m,
                 _lib.fptr(gradxyz1, "gradxyz1"), _lib.fptr(gradxyz2, "gradxyz2"),
-                _lib.stream_of(xyz1))
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(xyz1))
         _lib.check(code, "sn_chamfer_backward")
 
     @staticmethod

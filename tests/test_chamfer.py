@@ -108,9 +108,12 @@ def test_hip_matches_golden(golden_dir, dev):
         d1, d2, i1, i2 = _idx_hip(z["xyz1"], z["xyz2"], dev)
         assert np.array_equal(i1, z["idx1"]) and np.array_equal(i2, z["idx2"]), f
         assert np.array_equal(d1, z["dist1"]) and np.array_equal(d2, z["dist2"]), f
+        # backward: the gather over sorted inverse lists adds the reference CPU path's terms in its order --
+        # bit-equal to the goldens from the reference's own build, and bit-reproducible
         _, _, g1, g2 = _run_hip(z["xyz1"], z["xyz2"], z["graddist1"], z["graddist2"], dev)
-        np.testing.assert_allclose(g1, z["gradxyz1"], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(g2, z["gradxyz2"], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(g1, z["gradxyz1"]) and np.array_equal(g2, z["gradxyz2"]), f
+        _, _, h1, h2 = _run_hip(z["xyz1"], z["xyz2"], z["graddist1"], z["graddist2"], dev)
+        assert np.array_equal(g1, h1) and np.array_equal(g2, h2), f
 
 
 @pytest.mark.gpu
@@ -213,3 +216,26 @@ def test_hip_full_size_properties(dev):
     assert np.array_equal(o[2], i1[[0, 31]].cpu().numpy())
     assert np.array_equal(o[1], d2[[0, 31]].cpu().numpy())
     assert np.array_equal(o[3], i2[[0, 31]].cpu().numpy())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,m,kind", [(2, 3000, 1700, "uniform"), (1, 5000, 5000, "far"), (3, 513, 2049, "lattice"),
+                                        (1, 20000, 7, "uniform")])
+def test_hip_backward_bit_exact_incl_long_inverse_lists(b, n, m, kind, dev):
+    """Backward against the oracle (= the reference CPU order), bit for bit.  "far": every query of one cloud
+    shares ONE neighbour in the other (an inverse list of thousands of entries: the heap-sort path); the
+    7-point cloud gives lists of ~3000 entries each."""
+    rng = np.random.default_rng(n + m)
+    x = rng.random((b, n, 3), dtype=np.float32)
+    y = rng.random((b, m, 3), dtype=np.float32)
+    if kind == "far":
+        y = y * 0.01 + 40.0
+    if kind == "lattice":
+        x = (rng.integers(0, 5, (b, n, 3)) / 4).astype(np.float32)
+        y = (rng.integers(0, 5, (b, m, 3)) / 4).astype(np.float32)
+    gd1 = rng.random((b, n), dtype=np.float32)
+    gd2 = rng.random((b, m), dtype=np.float32)
+    _, _, i1, i2 = oracle.chamfer_forward(x, y, mt=True)
+    r1, r2 = oracle.chamfer_backward(x, y, gd1, gd2, i1, i2)
+    _, _, g1, g2 = _run_hip(x, y, gd1, gd2, dev)
+    assert np.array_equal(g1, r1) and np.array_equal(g2, r2)

@@ -80,6 +80,37 @@ def test_emd_bench_configuration_bit_exact(b, kind, seed, dev):
 
 
 @pytest.mark.gpu
+def test_emd_whole_benched_batch_bit_exact(dev):
+    """All 32 clouds of bench.py's batch (seed 1234): the configuration in which every team of the persistent
+    auction is one XCD's share of a ticket block (B >= 32) -- assignment, dist and the pair counter."""
+    x, y = _clouds(32, "uniform", 1234)
+    d0, a0, aux = oracle.emd_forward(x, y, 0.005, 50, mt=True, return_aux=True)
+    (d, a), st = _emd_raw(x, y, 0.005, 50, dev)
+    assert np.array_equal(a.cpu().numpy(), a0)
+    assert np.array_equal(d.cpu().numpy(), d0)
+    assert int(st[0]) == aux["pairs_eff"]
+    (d2, a2), _ = _emd_raw(x, y, 0.005, 50, dev)          # run to run: bit-identical
+    assert torch.equal(a, a2) and torch.equal(d, d2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,iters", [(33, 2048, 30), (70, 1024, 25), (300, 1024, 8), (7, 4096, 12), (16, 2048, 20)])
+def test_emd_team_geometries(b, n, iters, dev):
+    """Batch sizes that change the persistent auction's team geometry: 33 / 70 clouds (teams of 4 / 2
+    workgroups per cloud), 300 (teams of one workgroup serving several clouds in turn), 7 and 16 (contiguous
+    teams of 32 / 16 workgroups spanning XCDs).  Every word the workgroups exchange goes through coherent
+    accesses without fences: any stale read shows up here as a diverging assignment."""
+    g = torch.Generator().manual_seed(b * 7 + n)
+    x = torch.rand(b, n, 3, generator=g).numpy()
+    y = torch.rand(b, n, 3, generator=g).numpy()
+    d0, a0, aux = oracle.emd_forward(x, y, 0.005, iters, mt=True, return_aux=True)
+    (d, a), st = _emd_raw(x, y, 0.005, iters, dev)
+    assert np.array_equal(a.cpu().numpy(), a0)
+    assert np.array_equal(d.cpu().numpy(), d0)
+    assert int(st[0]) == aux["pairs_eff"]
+
+
+@pytest.mark.gpu
 def test_emd_unassigned_trace_equals_oracle(dev):
     """Per-iteration trace: running k iterations counts n * sum_{it<k} unass[it] pairs on the
     device, so the differences of the counter over k = 1..50 are the unassigned counts."""
