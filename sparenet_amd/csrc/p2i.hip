@@ -251,7 +251,7 @@ constexpr int kCell = 8;
 constexpr int kMaxRadii = 4;
 
 struct RadiiArg {
-  float radius[kMaxRadii], s_max[kMaxRadii], rev_scale[kMaxRadii];
+  float radius[kMaxRadii], s_max[kMaxRadii], rev_scale[kMaxRadii], inv_r2[kMaxRadii];
   float s_max_all;  // largest s_max
   int halo;         // cells to look at on each side
 };
@@ -337,6 +337,17 @@ __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
     const int pos = atomicAdd(&offs[b * cells_y * cells_x + c], 1);
     srec[pos] = make_float4(py, px, channels == 1 ? feat[pid] : 0.f, __int_as_float(pid));
   }
+}
+
+// Upper bound of the kernel weight (cos(pi r / R) + 1) / 2 from the squared distance alone, u = r^2 / R^2 in
+// [0, 1]: the alternating series 1 - (pi^2/4) u + (pi^4/48) u^2 - (pi^6/1440) u^3 + (pi^8/80640) u^4 - ...
+// cut after a positive term lies above the function (terms decrease), by at most 0.013 u^5.  Four FMAs instead
+// of sqrt + cos (both quarter rate); it only ever decides whether a pair is worth the exact evaluation.
+__device__ __forceinline__ float weight_bound(float u) {
+  float p = __builtin_fmaf(u, 0.1176653f, -0.6676340f);
+  p = __builtin_fmaf(u, p, 2.0293561f);
+  p = __builtin_fmaf(u, p, -2.4674011f);
+  return __builtin_fmaf(u, p, 1.0f);
 }
 
 struct GatherHit {
@@ -463,10 +474,9 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
         const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
         const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
         const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
-        const float rmin = __builtin_amdgcn_sqrtf(smin) * 0.99999f;
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const float wq = __builtin_amdgcn_cosf(rmin * ra.rev_scale[k]) * 0.5f + 0.5f + 4e-5f;
+          const float wq = weight_bound(__builtin_fminf(smin * ra.inv_r2[k], 1.0f)) + 4e-5f;
           const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
           keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub >= tile_min[k]);
         }
@@ -485,14 +495,12 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
         const float s2 = sq2(dx, dy);
         const float f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), i));
         // feature * weight <= f * max(w +- 2e-5, 0): the slack goes up for f >= 0, down otherwise
-        const float w_slack = f >= 0.f ? 2e-5f : -2e-5f;  // wave-uniform
-        const float rad = __builtin_amdgcn_sqrtf(s2);  // ~1 ulp: only feeds the bound
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
           if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
           const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
-          const float wq = __builtin_fmaf(__builtin_amdgcn_cosf(rad * ra.rev_scale[k]), 0.5f, 0.5f + w_slack);
-          const float ub = f * __builtin_fmaxf(wq, 0.f);
+          // feature * weight <= f * bound for f >= 0; a negative feature times a weight >= 0 is <= 0
+          const float ub = f >= 0.f ? f * (weight_bound(__builtin_fminf(s2 * ra.inv_r2[k], 1.0f)) + 2e-5f) : 0.f;
           const bool pass = ink && ub >= best[k];  // can still reach (or tie with) the best
           const unsigned long long m = __ballot(pass);
           GDIAG(dg_evalk++; dg_hits += __popcll(m); dg_hitc += m ? 1 : 0;)
@@ -944,6 +952,7 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
     ra.radius[k] = radii[k];
     ra.s_max[k] = max_sq_inside_host(radii[k]);
     ra.rev_scale[k] = 0.5f / radii[k];  // r*pi/R radians = r/(2R) revolutions
+    ra.inv_r2[k] = 1.0f / (radii[k] * radii[k]);
     ra.s_max_all = ra.s_max[k] > ra.s_max_all ? ra.s_max[k] : ra.s_max_all;
     rmax = radii[k] > rmax ? radii[k] : rmax;
   }
