@@ -215,6 +215,27 @@ int sn_p2i_sum_backward(const float *out_grad, const float *points,
                         int channels, int batch, int h, int w, float radius,
                         float *points_grad, float *feat_grad, void *stream);
 
+/* float64 tensors: the reference dispatches its functors on float and double (p2i_max.h:177,218,
+ * p2i_sum.h:162,201) and its own test is a float64 gradcheck (cuda/p2i_op/p2i_test.py:23-35).  Same
+ * semantics as the fp32 entry points above (lowest point id on equal values), simple atomics-based
+ * kernels -- the rendering path of SpareNet itself is fp32. */
+size_t sn_p2i_f64_workspace_bytes(int batch, int channels, int h, int w);
+int sn_p2i_max_forward_f64(const double *points, const double *point_features, const int *batch_inds,
+                           const double *background, int npoints, int channels, int batch, int h, int w,
+                           double kernel_radius, double *out, int *out_point_ids, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int sn_p2i_max_backward_f64(const double *out_grad, const int *out_point_ids, const double *points,
+                            const double *point_features, int npoints, int channels, int batch, int h,
+                            int w, double kernel_radius, double *points_grad, double *point_features_grad,
+                            double *background_grad, void *stream);
+int sn_p2i_sum_forward_f64(const double *points, const double *point_features, const int *batch_inds,
+                           int npoints, int channels, int batch, int h, int w, double kernel_radius,
+                           double *out, void *stream);
+int sn_p2i_sum_backward_f64(const double *out_grad, const double *points, const double *point_features,
+                            const int *batch_inds, int npoints, int channels, int batch, int h, int w,
+                            double kernel_radius, double *points_grad, double *point_features_grad,
+                            void *stream);
+
 /* ---------------------------------------------------------- EdgeConv k-NN graph
  * replaces knn() / get_graph_feature() of models/sparenet_generator.py:852-906 (GPU branch:
  * the un-vendored KNN_CUDA 0.2 wheel).  inner[b,n,n] = x^T x (a plain batched GEMM, computed

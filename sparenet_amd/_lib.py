@@ -37,7 +37,7 @@ def lib():
         for name in ("sn_emd_workspace_bytes", "sn_emd_diag_offset", "sn_p2i_max_workspace_bytes",
                      "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes", "sn_mds_workspace_bytes", "sn_p2i_max_backward_workspace_bytes",
                      "sn_p2i_max_multi_workspace_bytes",
-                     "sn_p2i_max_backward_multi_workspace_bytes", "sn_chamfer_workspace_bytes", "sn_chamfer_backward_workspace_bytes",
+                     "sn_p2i_max_backward_multi_workspace_bytes", "sn_chamfer_workspace_bytes", "sn_chamfer_backward_workspace_bytes", "sn_p2i_f64_workspace_bytes",
                      "sn_graph_feature_backward_workspace_bytes", "sn_knn_workspace_bytes"):
             if hasattr(_lib, name):
                 getattr(_lib, name).restype = ctypes.c_size_t
@@ -72,6 +72,10 @@ def fptr(t, name):
 
 def iptr(t, name):
     return ptr(t, torch.int32, name)
+
+
+def dptr(t, name):
+    return ptr(t, torch.float64, name)
 
 
 def stream_of(t):

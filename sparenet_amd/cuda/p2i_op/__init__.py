@@ -1,7 +1,9 @@
 """p2i -- paint point-cloud features onto a 2-D feature map.  Host-side mirror of
 cuda/p2i_op/__init__.py (P2ISumFunction :22-56, P2IMaxFunction :59-93, p2i()
-:99-131, custom_fun :133), backed by sn_p2i_{max,sum}_{forward,backward}
-(include/sparenet_hip.h).  fp32 CUDA tensors only.
+:99-131, custom_fun :133), backed by sn_p2i_{max,sum}_{forward,backward}[_f64]
+(include/sparenet_hip.h).  float32 (the rendering path: binned gather, exact fixed-point
+backward) and float64 (the reference dispatches both; its own test is a float64 gradcheck)
+CUDA tensors.
 """
 import ctypes
 
@@ -36,6 +38,18 @@ class _Ext:
         n, c, b, h, w = _shapes(points, point_features, background)
         out = torch.empty_like(background)
         ids = torch.empty(background.shape, dtype=torch.int32, device=background.device)
+        if points.dtype == torch.float64:
+            with torch.cuda.device_of(background):
+                nbytes = _lib.lib().sn_p2i_f64_workspace_bytes(b, c, h, w)
+                ws = torch.empty(nbytes, dtype=torch.uint8, device=background.device)
+                code = _lib.lib().sn_p2i_max_forward_f64(
+                    _lib.dptr(points, "points"), _lib.dptr(point_features, "point_features"),
+                    _lib.iptr(batch_inds, "batch_inds"), _lib.dptr(background, "background"),
+                    n, c, b, h, w, ctypes.c_double(kernel_radius), _lib.dptr(out, "out"),
+                    _lib.iptr(ids, "out_point_ids"), ctypes.c_void_p(ws.data_ptr()),
+                    ctypes.c_size_t(nbytes), _lib.stream_of(background))
+            _lib.check(code, "sn_p2i_max_forward_f64")
+            return out, ids
         with torch.cuda.device_of(background):
             nbytes = _lib.lib().sn_p2i_max_workspace_bytes(b, c, h, w)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=background.device)
@@ -82,6 +96,16 @@ class _Ext:
         points_grad = torch.empty_like(points)
         feat_grad = torch.empty_like(point_features)
         bg_grad = torch.empty_like(out_grad)
+        if points.dtype == torch.float64:
+            with torch.cuda.device_of(out_grad):
+                code = _lib.lib().sn_p2i_max_backward_f64(
+                    _lib.dptr(out_grad, "out_grad"), _lib.iptr(out_point_ids, "out_point_ids"),
+                    _lib.dptr(points, "points"), _lib.dptr(point_features, "point_features"),
+                    n, c, b, h, w, ctypes.c_double(kernel_radius), _lib.dptr(points_grad, "points_grad"),
+                    _lib.dptr(feat_grad, "point_features_grad"), _lib.dptr(bg_grad, "background_grad"),
+                    _lib.stream_of(out_grad))
+            _lib.check(code, "sn_p2i_max_backward_f64")
+            return points_grad, feat_grad, bg_grad
         with torch.cuda.device_of(out_grad):
             nbytes = _lib.lib().sn_p2i_max_backward_workspace_bytes(b, c, h, w)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=out_grad.device)
@@ -126,6 +150,14 @@ class _Ext:
             raise ValueError("p2i: only kernel_kind 0 ('cos') exists")
         n, c, b, h, w = _shapes(points, point_features, background)
         out = background.clone()
+        if points.dtype == torch.float64:
+            with torch.cuda.device_of(background):
+                code = _lib.lib().sn_p2i_sum_forward_f64(
+                    _lib.dptr(points, "points"), _lib.dptr(point_features, "point_features"),
+                    _lib.iptr(batch_inds, "batch_inds"), n, c, b, h, w, ctypes.c_double(kernel_radius),
+                    _lib.dptr(out, "out"), _lib.stream_of(background))
+            _lib.check(code, "sn_p2i_sum_forward_f64")
+            return out
         with torch.cuda.device_of(background):
             code = _lib.lib().sn_p2i_sum_forward(
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
@@ -142,6 +174,15 @@ class _Ext:
         b, _, h, w = out_grad.shape
         points_grad = torch.empty_like(points)
         feat_grad = torch.empty_like(point_features)
+        if points.dtype == torch.float64:
+            with torch.cuda.device_of(out_grad):
+                code = _lib.lib().sn_p2i_sum_backward_f64(
+                    _lib.dptr(out_grad, "out_grad"), _lib.dptr(points, "points"),
+                    _lib.dptr(point_features, "point_features"), _lib.iptr(batch_inds, "batch_inds"),
+                    n, c, b, h, w, ctypes.c_double(kernel_radius), _lib.dptr(points_grad, "points_grad"),
+                    _lib.dptr(feat_grad, "point_features_grad"), _lib.stream_of(out_grad))
+            _lib.check(code, "sn_p2i_sum_backward_f64")
+            return points_grad, feat_grad
         with torch.cuda.device_of(out_grad):
             code = _lib.lib().sn_p2i_sum_backward(
                 _lib.fptr(out_grad, "out_grad"), _lib.fptr(points, "points"),
@@ -194,6 +235,10 @@ class P2IMaxFunction(Function):
     def backward(ctx, out_grad):
         points, point_features, winner_ids, batch_inds = ctx.saved_tensors
         kind, radius = ctx.kind_radius
+        if points.dtype == torch.float64:
+            g_points, g_feat, g_bg = ext.p2i_max_backward_gpu(
+                out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radius)
+            return g_points, g_feat, None, g_bg, None, None
         g_points, g_feat, g_bg = ext.p2i_max_backward_multi_gpu(
             out_grad.contiguous().unsqueeze(0), winner_ids.unsqueeze(0),
             *_c(points, point_features), kind, [radius])

@@ -331,3 +331,84 @@ def test_hip_empty_and_out_of_image_inputs(dev):
     assert torch.equal(o, bg)
     o.sum().backward()
     assert float(far.grad.abs().sum()) == 0.0 and float(feat.grad.abs().sum()) == 0.0
+
+
+# ------------------------------------------------------------------ float64 (the reference's own test surface)
+def _np_p2i_f64(points, feat, bi, bg, radius, reduce):
+    """Plain numpy float64 restatement of p2i_{sum,max}.h + utility.h:82-100 on pixel coordinates."""
+    out = bg.copy()
+    ids = np.full(bg.shape, -1, np.int64)
+    B, C, H, W = bg.shape
+    for pid in range(points.shape[0]):
+        b = bi[pid]
+        if b < 0 or b >= B:
+            continue
+        py, px = points[pid]
+        x0, x1 = np.clip([np.floor(px - radius), np.ceil(px + radius)], 0, W - 1).astype(int)
+        y0, y1 = np.clip([np.floor(py - radius), np.ceil(py + radius)], 0, H - 1).astype(int)
+        for x in range(x0, x1 + 1):
+            for y in range(y0, y1 + 1):
+                r = np.sqrt((x - px) ** 2 + (y - py) ** 2)
+                if r <= radius:
+                    wgt = np.cos(r * np.pi / radius) * 0.5 + 0.5
+                    for c in range(C):
+                        v = feat[pid, c] * wgt
+                        if reduce == "sum":
+                            out[b, c, y, x] += v
+                        elif out[b, c, y, x] < v:
+                            out[b, c, y, x] = v
+                            ids[b, c, y, x] = pid
+    return out, ids
+
+
+@pytest.mark.gpu
+def test_hip_float64_known_answer_and_numpy(dev):
+    """cuda/p2i_op/p2i_test.py:10-20 (a point at the image centre, R = 2, 8x8: 0.722008 on the four centre
+    pixels, 0.104375 on the ring) and random float64 inputs against a numpy restatement."""
+    from sparenet_amd.cuda.p2i_op import ext, p2i
+
+    f64 = dict(dtype=torch.float64, device=dev)
+    points = torch.zeros(1, 2, **f64)
+    feats = torch.ones(1, 3, **f64)
+    bi = torch.arange(1, dtype=torch.int32, device=dev)
+    bg = torch.zeros(1, 3, 8, 8, **f64)
+    for reduce in ("sum", "max"):
+        out = p2i(points, feats, bi, bg, 2, "cos", reduce)
+        assert out.dtype == torch.float64
+        o = out.cpu().numpy()
+        centre = np.cos(np.sqrt(0.5) * np.pi / 2) * 0.5 + 0.5           # 0.722008...
+        ring = np.cos(np.sqrt(2.5) * np.pi / 2) * 0.5 + 0.5             # 0.104375...
+        assert abs(centre - 0.722008) < 1e-6 and abs(ring - 0.104375) < 1e-6
+        np.testing.assert_allclose(o[0, :, 3:5, 3:5], centre, rtol=1e-13)
+        np.testing.assert_allclose(o[0, 0, 2, 3], ring, rtol=1e-12)
+        assert o[0, 0, 0, 0] == 0 and np.count_nonzero(o[0, 0]) == 12
+    rng = np.random.default_rng(3)
+    B, n, C, S, R = 2, 60, 2, 12, 2.5
+    pts = (rng.random((B * n, 2)) * 1.3 - 0.15) * (S - 1)
+    ft = rng.standard_normal((B * n, C))
+    bidx = rng.integers(-1, B + 1, B * n).astype(np.int32)
+    bgn = rng.standard_normal((B, C, S, S)) * 0.1
+    T = lambda a: torch.from_numpy(a).to(dev)
+    out, ids = ext.p2i_max_forward_gpu(T(pts), T(ft), T(bidx), T(bgn), 0, R)
+    ro, ri = _np_p2i_f64(pts, ft, bidx, bgn, R, "max")
+    np.testing.assert_allclose(out.cpu().numpy(), ro, rtol=1e-13, atol=1e-15)
+    assert np.array_equal(ids.cpu().numpy(), ri)
+    so = ext.p2i_sum_forward_gpu(T(pts), T(ft), T(bidx), T(bgn), 0, R)
+    np.testing.assert_allclose(so.cpu().numpy(), _np_p2i_f64(pts, ft, bidx, bgn, R, "sum")[0], rtol=1e-11, atol=1e-13)
+
+
+@pytest.mark.gpu
+def test_hip_float64_gradcheck_like_the_reference(dev):
+    """The reference's own test (cuda/p2i_op/p2i_test.py:23-35): float64 gradcheck of p2i, sum and max."""
+    from torch.autograd import gradcheck
+
+    from sparenet_amd.cuda.p2i_op import p2i
+
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        points = torch.randn(2, 2, dtype=torch.float64, generator=g).to(dev).requires_grad_(True)
+        feats = torch.randn(2, 3, dtype=torch.float64, generator=g).to(dev).requires_grad_(True)
+        bi = torch.zeros(2, dtype=torch.int32, device=dev)
+        bg = torch.randn(1, 3, 8, 8, dtype=torch.float64, generator=g).to(dev).requires_grad_(True)
+        assert gradcheck(p2i, inputs=(points, feats, bi, bg, 2, "cos", "sum"))
+        assert gradcheck(p2i, inputs=(points, feats, bi, bg, 2, "cos", "max"))
