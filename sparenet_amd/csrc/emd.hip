@@ -471,22 +471,24 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
 //   * Teams are formed from a TICKET taken at start, not from blockIdx: a workgroup only ever waits for
 //     workgroups that have started, and at most one block of teams per launch is incomplete at any time,
 //     so concurrent launches on other streams cannot starve each other (each can hold <= 63 CUs waiting).
-//     With >= 32 clouds a team is the 8 tickets of one residue class mod 8 inside a block of 64 -- one XCD
-//     under the observed round-robin placement (speed only); fewer clouds get larger, contiguous teams.
+//     With >= 32 clouds a team is G consecutive tickets of ONE XCD's counter (the XCD read from the hardware
+//     register: its L2 then keeps the cloud's streams; speed only); fewer clouds get larger, contiguous
+//     teams from one global counter.
 //   * Every spin is bounded; a timeout raises ctl.abort, every workgroup of the launch leaves, and
 //     sn_emd_forward reports it on the next call that checks (SN_EMD_CHECK=1: immediately).
 // =======================================================================================
 struct AuctionCtl {  // zeroed by a memset node before every launch
   unsigned ticket;
   unsigned abort;
-  unsigned pad[30];
+  unsigned xticket[8];  // one ticket counter per XCD (teams of the XCD-local geometry)
+  unsigned pad[22];
   unsigned bar[1];  // [teams * 32]: one counter per team, 128 bytes apart
 };
 
 struct TeamGeom {
   int G;       // workgroups per team (power of two)
   int teams;   // teams in the launch
-  int xcd;     // 1: teams are residue classes mod 8 inside blocks of 8 G tickets
+  int xcd;     // 1: a team = G consecutive tickets of one XCD's counter (XCD-local teams)
 };
 
 __host__ __device__ inline TeamGeom team_geometry(int B, int W) {
@@ -812,21 +814,32 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
     gacc[tid].arrived = 0;
   }
   if (tid < kRankBins) s_bins[tid] = 0;
-  if (tid == 0)
-    s_ticket = (int)__hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int G = a.tg.G;
+  if (tid == 0) {
+    int t = -1;
+    if (a.tg.xcd) {
+      // A team = G consecutive tickets of ONE XCD's counter: its workgroups share that XCD's L2, where the
+      // cloud's streams then stay from iteration to iteration.  The XCD is read from the hardware register
+      // (the ticket ORDER says nothing about placement).  A counter only hands out its share of slots; a
+      // workgroup on an over-subscribed XCD walks on to the next counter -- every slot is taken whatever
+      // the placement, which only ever costs speed.
+      const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);  // HW_REG_XCC_ID[3:0]
+      const int cap = (a.tg.teams / 8) * G;
+      for (int i = 0; i < 8 && t < 0; ++i) {
+        const int x = (xcc + i) & 7;
+        const int k = (int)__hip_atomic_fetch_add(&a.ctl->xticket[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < cap) t = ((k / G) * 8 + x) * G + k % G;  // team * G + member
+      }
+    } else {
+      t = (int)__hip_atomic_fetch_add(&a.ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_ticket = t;
+  }
   __syncthreads();
   const int ticket = s_ticket;
-  const int G = a.tg.G;
-  int team, m;
-  if (a.tg.xcd) {  // blocks of 8 G tickets: residue class mod 8 = team inside the block
-    const int blk = ticket / (8 * G), r = ticket % (8 * G);
-    team = blk * 8 + (r & 7);
-    m = r >> 3;
-  } else {
-    team = ticket / G;
-    m = ticket % G;
-  }
-  if (team >= a.tg.teams) return;  // surplus workgroups of a grid that is no multiple of the team size
+  if (ticket < 0) return;  // no slot left: surplus workgroup of a grid larger than teams x G
+  const int team = ticket / G, m = ticket % G;
+  if (team >= a.tg.teams) return;
   TeamSync ts = {a.ctl->bar + (size_t)team * 32, &a.ctl->abort, 0u, G};
 
   const int n = a.n, nsb = n >> 6;
