@@ -80,6 +80,8 @@ def parse():
                     help="time the sequential one-stream step instead of the two-stream one")
     ap.add_argument("--no-other-ops", action="store_true",
                     help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
+    ap.add_argument("--per-view-render", action="store_true",
+                    help="render view by view (the reference's loop) instead of all 8 views in one pass")
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1: skip the second timed region with the other scaling mode")
     return ap.parse_args()
@@ -102,7 +104,7 @@ class HotPath:
     """One training-step worth of loss/render ops, composed like the reference runners
     (runners/sparenet_runner.py:83-108, runners/sparenet_gan_runner.py:212-225)."""
 
-    def __init__(self, dev, radius_list):
+    def __init__(self, dev, radius_list, per_view=False):
         from sparenet_amd.cuda.chamfer_distance import ChamferDistance
         from sparenet_amd.cuda.emd.emd_module import emd_forward_raw, emdFunction
         from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
@@ -117,6 +119,7 @@ class HotPath:
         self.expansion = expansionPenaltyModule()
         self.render = ComputeDepthMaps("orthorgonal", 1.0, IMG).to(dev)
         self.radius_list = radius_list
+        self.per_view = per_view
         self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
         self.last_mean_mst = None
         self.side = None
@@ -142,12 +145,19 @@ class HotPath:
         return _Counted.apply(pred, gt)
 
     def _render_all(self, pred):
+        """All 8 views x radii, forward + backward; loss = sum over the views of the mean map.  By default the
+        views are rendered in ONE pass (ComputeDepthMaps.forward_views: the views join the batch; maps bit-equal
+        to the per-view calls); --per-view-render issues the reference's view-by-view loop instead."""
         p4 = (pred.detach() - 0.5).requires_grad_(True)
-        acc = None
-        for v in range(N_VIEWS):
-            maps = self.render(p4, view_id=v, radius_list=self.radius_list)
-            s = maps.mean()
-            acc = s if acc is None else acc + s
+        if self.per_view:
+            acc = None
+            for v in range(N_VIEWS):
+                maps = self.render(p4, view_id=v, radius_list=self.radius_list)
+                s = maps.mean()
+                acc = s if acc is None else acc + s
+        else:
+            maps = self.render.forward_views(p4, range(N_VIEWS), self.radius_list)       # [V,B,R,S,S]
+            acc = maps.mean(dim=(1, 2, 3, 4)).sum()
         acc.backward()
         return acc
 
@@ -423,7 +433,7 @@ def main():
 
     pred, gt = make_inputs(dev, rank, world, args.scaling)
     b_local = pred.size(0)
-    hp = HotPath(dev, radius_list)
+    hp = HotPath(dev, radius_list, args.per_view_render)
     lib = hp.lib.lib()
     build_id = lib.sn_build_id().decode()
 
@@ -593,6 +603,7 @@ def main():
                 "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
                 "emd_iters": EMD_ITERS, "radius_list": radius_list,
                 "image": IMG, "views": N_VIEWS, "streams": 2 if overlap else 1, "library_build": build_id,
+                "render": "view by view" if args.per_view_render else "8 views in one pass (forward_views)",
             },
             "other_scaling": other,
             "pairs_per_step": pairs_total / args.steps / world,

@@ -277,6 +277,18 @@ int sn_depth_project_backward(const float *data, long npoints, const float *matr
                               const float *g_pixel, const float *g_feat,
                               void *workspace32, float *g_data, void *stream);
 
+/* The same for up to 8 views at once (the views of a ComputeDepthMaps sweep become part of the batch:
+ * pixel / z / feat are [nviews, npoints], zminmax [nviews, 2], normalisation per view as in the reference;
+ * g_data [npoints, 3] receives the sum over the views).  matrices16: nviews x 16 host floats.
+ * workspace: 32 bytes per view. */
+int sn_depth_project_forward_views(const float *data, long npoints, const float *matrices16, int nviews,
+                                   float extent, float *pixel, float *z, unsigned *zminmax, float *feat,
+                                   void *stream);
+int sn_depth_project_backward_views(const float *data, long npoints, const float *matrices16, int nviews,
+                                    float extent, const float *z, const unsigned *zminmax,
+                                    const float *g_pixel, const float *g_feat, void *workspace,
+                                    float *g_data, void *stream);
+
 /* ----------------------------------------------------------------- gridding
  * replaces gridding.forward / backward (cuda/gridding/gridding_cuda.cpp:44-67,
  *          94-95; gridding.cu:29-211, 213-335).  ptcloud[b,npts,3] already

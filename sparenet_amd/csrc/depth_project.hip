@@ -212,3 +212,212 @@ extern "C" int sn_depth_project_backward(const float *data, long npoints, const 
       counts, g_data);
   return sn::launch_status("sn_depth_project_backward");
 }
+
+
+// ---------------------------------------------------------------------------------------------------
+// All views of a ComputeDepthMaps sweep in one set of launches.  The per-view path above costs ~10 small
+// launches per view (projection, feature, binning, reductions ...), each far too short to fill the chip;
+// a renderer call over V views is V x B independent images, so the views simply become part of the batch:
+// pixel / z / feat are [V, n], zminmax [V, 2] (the depth normalisation stays PER VIEW over the whole input
+// tensor, utils/p2i_utils.py:226), and the splat sees V x B images.  blockIdx.y = view.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kMaxViews = 8;
+struct MatV {
+  Mat4 v[kMaxViews];
+};
+
+__global__ __launch_bounds__(1024) void depth_project_views_kernel(const float *__restrict__ data, long n, MatV M,
+                                                                  float extent, float2 *__restrict__ pixel,
+                                                                  float *__restrict__ zbuf,
+                                                                  unsigned *__restrict__ zminmax) {
+  __shared__ unsigned red[2][16];
+  const int view = blockIdx.y;
+  const Mat4 &Mv = M.v[view];
+  pixel += (size_t)view * n;
+  zbuf += (size_t)view * n;
+  unsigned lo = 0xffffffffu, hi = 0u;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float o[4];
+    transform(Mv, data[i * 3 + 0], data[i * 3 + 1], data[i * 3 + 2], o);
+    const float px = o[0] / o[3], py = o[1] / o[3], pz = o[2] / o[3];
+    pixel[i] = make_float2((-py + 1.f) / 2.f * extent, (px + 1.f) / 2.f * extent);
+    zbuf[i] = pz;
+    const unsigned k = ord_bits(pz);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    const unsigned a = (unsigned)__shfl_xor((int)lo, m), b = (unsigned)__shfl_xor((int)hi, m);
+    lo = a < lo ? a : lo;
+    hi = b > hi ? b : hi;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = lo;
+    red[1][threadIdx.x >> 6] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      lo = red[0][w] < lo ? red[0][w] : lo;
+      hi = red[1][w] > hi ? red[1][w] : hi;
+    }
+    atomicMin(zminmax + 2 * view + 0, lo);
+    atomicMax(zminmax + 2 * view + 1, hi);
+  }
+}
+
+__global__ __launch_bounds__(256) void depth_feature_views_kernel(const float *__restrict__ zbuf, long n,
+                                                                  const unsigned *__restrict__ zminmax,
+                                                                  float *__restrict__ feat) {
+  const int view = blockIdx.y;
+  const float zmin = unord_bits(zminmax[2 * view]), zmax = unord_bits(zminmax[2 * view + 1]);
+  const float range = zmax - zmin;
+  zbuf += (size_t)view * n;
+  feat += (size_t)view * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    feat[i] = 1.0f - (zbuf[i] - zmin) / range;
+}
+
+__global__ __launch_bounds__(256) void depth_reduce_views_kernel(const float *__restrict__ zbuf,
+                                                                 const float *__restrict__ g_feat, long n,
+                                                                 const unsigned *__restrict__ zminmax,
+                                                                 double *__restrict__ sums_all) {
+  __shared__ double red[2][4];
+  __shared__ unsigned cred[2][4];
+  const int view = blockIdx.y;
+  double *sums = sums_all + 4 * view;                      // {S_a, S_c, counts as two unsigned in one double slot...}
+  unsigned *counts = reinterpret_cast<unsigned *>(sums + 2);
+  zbuf += (size_t)view * n;
+  g_feat += (size_t)view * n;
+  const float zmin = unord_bits(zminmax[2 * view]), zmax = unord_bits(zminmax[2 * view + 1]);
+  const double r = (double)zmax - (double)zmin, r2 = r * r;
+  double sa = 0.0, sc = 0.0;
+  unsigned na = 0, nc = 0;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float z = zbuf[i];
+    const double g = g_feat[i];
+    sa += g * ((double)zmax - (double)z) / r2;
+    sc += g * ((double)z - (double)zmin) / r2;
+    na += z == zmin;
+    nc += z == zmax;
+  }
+  for (int m = 1; m < 64; m <<= 1) {
+    sa += __shfl_xor(sa, m);
+    sc += __shfl_xor(sc, m);
+    na += (unsigned)__shfl_xor((int)na, m);
+    nc += (unsigned)__shfl_xor((int)nc, m);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sa;
+    red[1][threadIdx.x >> 6] = sc;
+    cred[0][threadIdx.x >> 6] = na;
+    cred[1][threadIdx.x >> 6] = nc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) {
+      sa += red[0][w];
+      sc += red[1][w];
+      na += cred[0][w];
+      nc += cred[1][w];
+    }
+    atomicAdd(sums + 0, sa);
+    atomicAdd(sums + 1, sc);
+    if (na) atomicAdd(counts + 0, na);
+    if (nc) atomicAdd(counts + 1, nc);
+  }
+}
+
+// one thread per point: the contributions of all views meet in registers, one store
+__global__ __launch_bounds__(256) void depth_project_bwd_views_kernel(
+    const float *__restrict__ data, long n, MatV M, int nviews, float extent, const float *__restrict__ zbuf,
+    const unsigned *__restrict__ zminmax, const float2 *__restrict__ g_pixel, const float *__restrict__ g_feat,
+    const double *__restrict__ sums_all, float *__restrict__ g_data) {
+  const float half = extent * 0.5f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float x = data[i * 3 + 0], y = data[i * 3 + 1], zc = data[i * 3 + 2];
+    float acc[3] = {0.f, 0.f, 0.f};
+    for (int v = 0; v < nviews; ++v) {
+      const Mat4 &Mv = M.v[v];
+      const float zmin = unord_bits(zminmax[2 * v]), zmax = unord_bits(zminmax[2 * v + 1]);
+      const float range = zmax - zmin;
+      const double *sums = sums_all + 4 * v;
+      const unsigned *counts = reinterpret_cast<const unsigned *>(sums + 2);
+      float o[4];
+      transform(Mv, x, y, zc, o);
+      const float z = zbuf[(size_t)v * n + i];
+      float gpz = 0.f;
+      if (g_feat) {
+        const float ga = (float)(sums[0] / (double)counts[0]), gc = (float)(sums[1] / (double)counts[1]);
+        gpz = -g_feat[(size_t)v * n + i] / range + (z == zmin ? ga : 0.f) + (z == zmax ? gc : 0.f);
+      }
+      float gpx = 0.f, gpy = 0.f;
+      if (g_pixel) {
+        const float2 gp = g_pixel[(size_t)v * n + i];
+        gpy = -gp.x * half;
+        gpx = gp.y * half;
+      }
+      const float iw = 1.0f / o[3];
+      const float go0 = gpx * iw, go1 = gpy * iw, go2 = gpz * iw;
+      const float go3 = -(gpx * o[0] + gpy * o[1] + gpz * o[2]) * iw * iw;
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        acc[c] += Mv.m[c] * go0 + Mv.m[4 + c] * go1 + Mv.m[8 + c] * go2 + Mv.m[12 + c] * go3;
+    }
+    g_data[i * 3 + 0] = acc[0];
+    g_data[i * 3 + 1] = acc[1];
+    g_data[i * 3 + 2] = acc[2];
+  }
+}
+
+}  // namespace
+
+extern "C" int sn_depth_project_forward_views(const float *data, long npoints, const float *matrices16,
+                                              int nviews, float extent, float *pixel, float *z,
+                                              unsigned *zminmax, float *feat, void *stream) {
+  SN_REQUIRE(matrices16 && zminmax, "sn_depth_project_forward_views: null pointer");
+  SN_REQUIRE(npoints >= 0 && nviews >= 1 && nviews <= kMaxViews,
+             "sn_depth_project_forward_views: need 1 <= nviews <= 8 (got %d)", nviews);
+  hipStream_t s = sn::as_stream(stream);
+  for (int v = 0; v < nviews; ++v) {
+    SN_HIP(hipMemsetAsync(zminmax + 2 * v, 0xff, 4, s));
+    SN_HIP(hipMemsetAsync(zminmax + 2 * v + 1, 0, 4, s));
+  }
+  if (npoints == 0) return 0;
+  SN_REQUIRE(data && pixel && z && feat, "sn_depth_project_forward_views: null pointer");
+  MatV M;
+  for (int v = 0; v < nviews; ++v)
+    for (int i = 0; i < 16; ++i) M.v[v].m[i] = matrices16[v * 16 + i];
+  const long pb = (npoints + 1023) / 1024;
+  depth_project_views_kernel<<<dim3((unsigned)(pb > 64 ? 64 : pb), nviews), 1024, 0, s>>>(
+      data, npoints, M, extent, reinterpret_cast<float2 *>(pixel), z, zminmax);
+  depth_feature_views_kernel<<<dim3(blocks_for(npoints), nviews), 256, 0, s>>>(z, npoints, zminmax, feat);
+  return sn::launch_status("sn_depth_project_forward_views");
+}
+
+extern "C" int sn_depth_project_backward_views(const float *data, long npoints, const float *matrices16,
+                                               int nviews, float extent, const float *z,
+                                               const unsigned *zminmax, const float *g_pixel,
+                                               const float *g_feat, void *workspace256, float *g_data,
+                                               void *stream) {
+  SN_REQUIRE(matrices16 && zminmax && workspace256, "sn_depth_project_backward_views: null pointer");
+  SN_REQUIRE(nviews >= 1 && nviews <= kMaxViews, "sn_depth_project_backward_views: need 1 <= nviews <= 8");
+  if (npoints == 0) return 0;
+  SN_REQUIRE(data && z && g_data, "sn_depth_project_backward_views: null pointer");
+  hipStream_t s = sn::as_stream(stream);
+  MatV M;
+  for (int v = 0; v < nviews; ++v)
+    for (int i = 0; i < 16; ++i) M.v[v].m[i] = matrices16[v * 16 + i];
+  double *sums = static_cast<double *>(workspace256);   // per view: {S_a, S_c, (n_a, n_c), pad}
+  if (g_feat) {
+    SN_HIP(hipMemsetAsync(workspace256, 0, 32 * (size_t)nviews, s));
+    const int rb = blocks_for(npoints) < 48 ? blocks_for(npoints) : 48;
+    depth_reduce_views_kernel<<<dim3(rb, nviews), 256, 0, s>>>(z, g_feat, npoints, zminmax, sums);
+  }
+  depth_project_bwd_views_kernel<<<blocks_for(npoints), 256, 0, s>>>(
+      data, npoints, M, nviews, extent, z, zminmax, reinterpret_cast<const float2 *>(g_pixel), g_feat, sums,
+      g_data);
+  return sn::launch_status("sn_depth_project_backward_views");
+}

@@ -412,3 +412,30 @@ def test_hip_float64_gradcheck_like_the_reference(dev):
         bg = torch.randn(1, 3, 8, 8, dtype=torch.float64, generator=g).to(dev).requires_grad_(True)
         assert gradcheck(p2i, inputs=(points, feats, bi, bg, 2, "cos", "sum"))
         assert gradcheck(p2i, inputs=(points, feats, bi, bg, 2, "cos", "max"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("projection,radii", [("orthorgonal", [5.0, 7.0, 10.0]), ("perspective", [3.0])])
+def test_hip_all_views_in_one_pass_equal_per_view_calls(projection, radii, dev):
+    """ComputeDepthMaps.forward_views: the V views of a sweep joined to the batch -- maps bit-equal to V
+    separate forward() calls, and the gradient of the cloud equal to the sum of the per-view gradients."""
+    from sparenet_amd.utils.p2i_utils import ComputeDepthMaps
+
+    g = torch.Generator().manual_seed(8)
+    cdm = ComputeDepthMaps(projection, 1.0, 64).to(dev)
+    base = (torch.rand(3, 2000, 3, generator=g) - 0.5).to(dev)
+    w = torch.rand(8, 3, len(radii), 64, 64, generator=g).to(dev)
+    d1 = base.clone().requires_grad_(True)
+    all_maps = cdm.forward_views(d1, range(8), radii)
+    assert all_maps.shape == (8, 3, len(radii), 64, 64)
+    (all_maps * w).sum().backward()
+    d2 = base.clone().requires_grad_(True)
+    loss = 0
+    for v in range(8):
+        m = cdm(d2, view_id=v, radius_list=radii)
+        assert torch.equal(m, all_maps[v]), v
+        loss = loss + (m * w[v]).sum()
+    loss.backward()
+    np.testing.assert_allclose(d1.grad.cpu().numpy(), d2.grad.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    sub = cdm.forward_views(base, [6, 2], radii)
+    assert torch.equal(sub[0], all_maps[6]) and torch.equal(sub[1], all_maps[2])

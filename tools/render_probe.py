@@ -8,12 +8,16 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(1234)
 data = (torch.rand(32, 16384, 3, generator=g) - 0.5).to(dev)
 cdm = ComputeDepthMaps("orthorgonal", 1.0, 256).to(dev)
+PER_VIEW = os.environ.get("PER_VIEW") == "1"   # the reference's view-by-view loop instead of one pass
 def step():
     p = data.clone().requires_grad_(True)
-    acc = None
-    for v in range(8):
-        m = cdm(p, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
-        acc = m if acc is None else acc + m
+    if PER_VIEW:
+        acc = None
+        for v in range(8):
+            m = cdm(p, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
+            acc = m if acc is None else acc + m
+    else:
+        acc = cdm.forward_views(p, range(8), [5.0, 7.0, 10.0]).mean(dim=(1, 2, 3, 4)).sum()
     acc.backward()
 for _ in range(2): step()
 torch.cuda.synchronize()
