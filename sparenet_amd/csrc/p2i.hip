@@ -236,17 +236,12 @@ __global__ __launch_bounds__(256) void p2i_max_splat_kernel(
 // WAVE owns an 8x8 tile, lane = pixel, and walks the points of the (2H+1)^2 surrounding cells,
 // H = floor(Rmax / 8) + 1.  A cell row of an image is contiguous in the sorted arrays, so the
 // candidates arrive as 2H+1 ranges, fetched 64 at a time (one per lane) and broadcast with
-// v_readlane.  The running best of every pixel stays in registers; a candidate is only
-// evaluated exactly (fp64 cosine) when a cheap fp32 upper bound of feature*weight reaches the
-// pixel's current best -- those pairs go to a per-wave LDS queue and are drained 64 at a
-// time, the result meeting the pixel through a packed 64-bit LDS atomicMax (value bits << 32
-// | ~id), so equal values still resolve to the lowest point id and nothing depends on the
-// visiting order.  All radii of a ComputeDepthMaps call share the binning, the fetches and the
-// squared distances; the finished tile is written once as values + ids.
+// v_readlane.  Every in-range (candidate, pixel) pair gets a cheap fp32 value with a proven error bound; a pixel
+// keeps the three largest in registers and only the winner (and a runner-up inside the error band) is evaluated
+// with the reference's fp64 cosine at the end -- see p2i_gather_max_kernel.  Equal values still resolve to the
+// lowest point id and nothing depends on the visiting order.  All radii of a ComputeDepthMaps call share the
+// binning, the fetches and the squared distances; the finished tile is written once as values + ids.
 // ---------------------------------------------------------------------------------------
-#ifndef SN_P2I_DRAIN_STEPS
-#define SN_P2I_DRAIN_STEPS 0
-#endif
 constexpr int kCell = 8;
 constexpr int kMaxRadii = 4;
 
@@ -326,7 +321,9 @@ __global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(const int *__restric
 __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
     const float *__restrict__ points, const float *__restrict__ feat,
     const int *__restrict__ batch_inds, int *__restrict__ offs, float4 *__restrict__ srec,
-    int npoints, int channels, int batch, int h, int w, int cells_x, int cells_y) {
+    unsigned *__restrict__ fmax_bits, int npoints, int channels, int batch, int h, int w, int cells_x,
+    int cells_y) {
+  float fm = 0.f;  // largest |feature| of the binned points: scales the error bound of the gather's fast path
   for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
        pid += gridDim.x * blockDim.x) {
     const int b = batch_inds[pid];
@@ -336,50 +333,56 @@ __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
     if (c < 0) continue;
     const int pos = atomicAdd(&offs[b * cells_y * cells_x + c], 1);
     srec[pos] = make_float4(py, px, channels == 1 ? feat[pid] : 0.f, __int_as_float(pid));
+    for (int ch = 0; ch < channels; ++ch) fm = __builtin_fmaxf(fm, __builtin_fabsf(feat[(size_t)pid * channels + ch]));
   }
+  for (int m = 1; m < 64; m <<= 1) fm = __builtin_fmaxf(fm, __shfl_xor(fm, m));
+  // non-negative floats order like their bit patterns; the read first keeps 65k waves off one address
+  if ((threadIdx.x & 63) == 0 && __float_as_uint(fm) > *reinterpret_cast<volatile unsigned *>(fmax_bits))
+    atomicMax(fmax_bits, __float_as_uint(fm));
 }
 
-// Upper bound of the kernel weight (cos(pi r / R) + 1) / 2 from the squared distance alone, u = r^2 / R^2 in
-// [0, 1]: the alternating series sum_k (-1)^k pi^2k u^k / (2 (2k)!) cut after the (positive) u^6 term lies above
-// the function by at most 5.1e-5 (the u^7 term), and 7e-8 below it in fp32 -- inside the 2e-5 slack the callers
-// add.  Six FMAs instead of sqrt + cos (both quarter rate); it only decides whether a pair is worth the exact
-// evaluation.
-__device__ __forceinline__ float weight_bound(float u) {
-  float p = __builtin_fmaf(u, 9.64787155e-4f, -1.29034457e-2f);
-  p = __builtin_fmaf(u, p, 1.17665315e-1f);
-  p = __builtin_fmaf(u, p, -6.67631384e-1f);
-  p = __builtin_fmaf(u, p, 2.02935606f);
-  p = __builtin_fmaf(u, p, -2.46740110f);
-  return __builtin_fmaf(u, p, 1.0f);
-}
-
-struct GatherHit {
-  unsigned lane_k;  // pixel lane | radius index << 6
-  float s, f;       // dx*dx+dy*dy, feature
-  unsigned low;     // 0xFFFFFFFE - point id
-};
-
-#ifdef SN_P2I_DIAG  // survivor statistics of the gather (diag build only)
+#ifdef SN_P2I_DIAG  // statistics of the gather (diag build only)
 __device__ unsigned long long g_gather_diag[8];
 #define GDIAG(...) __VA_ARGS__
 #else
 #define GDIAG(...)
 #endif
 
-// C1 = single-channel features (ComputeDepthMaps): the feature travels in the sorted record.  As a run-time
-// test the per-channel load sat in a branch next to the record prefetch and hipcc covered both with one
-// s_waitcnt vmcnt(0) -- every batch of 64 candidates waited for the NEXT batch's records to arrive.
+// (cos(pi r / R) + 1) / 2 from u = r^2 / R^2 in [0, 1] as the Taylor series through u^9 (next term 1.8e-9), Horner in
+// fp32.  |weight32(u) - exact weight| <= 1.5e-6 covers: the fp32 Horner rounding (<= 5e-7), the two roundings of u
+// (<= 3e-7), and the reference rounding r = sqrtf(s) to a float before the cosine (<= 1e-7) -- see kWeightErr.
+__device__ __forceinline__ float weight32(float u) {
+  float p = __builtin_fmaf(u, -6.96522949e-8f, 2.15153479e-6f);
+  p = __builtin_fmaf(u, p, -5.23190525e-5f);
+  p = __builtin_fmaf(u, p, 9.64787155e-4f);
+  p = __builtin_fmaf(u, p, -1.29034457e-2f);
+  p = __builtin_fmaf(u, p, 1.17665315e-1f);
+  p = __builtin_fmaf(u, p, -6.67631384e-1f);
+  p = __builtin_fmaf(u, p, 2.02935606f);
+  p = __builtin_fmaf(u, p, -2.46740110f);
+  return __builtin_fmaf(u, p, 1.0f);
+}
+constexpr float kWeightErr = 1.5e-6f;
+
+// Binned gather with a DECIDE-CHEAP / EVALUATE-THE-WINNER split.  The reference's value is
+// feature * (float)(cos(r pi / R) / 2 + 1 / 2) with the cosine in double; evaluating that for every pair that
+// might raise a pixel's running maximum cost 27 % of the renderer (3.2 evaluations per pixel and radius: the
+// record-breaking count of a streaming maximum).  Now every in-range pair gets the fp32 series value `a`, which is
+// within EPS = max|feature| * kWeightErr of the exact one, and a pixel keeps the TOP THREE of them (value + sorted
+// position for the first two).  At the end only the winner is evaluated exactly -- and the runner-up too when it
+// lies within 2 EPS of the winner (then the exact values and the lowest point id decide, as before).  If even the
+// third lies within the band (equal points in triplicate ...) the pixel is settled by an exact walk over all its
+// candidates.  The background takes part as a candidate with an exact value and no id.  Why this is exact: the
+// true winner T has a_T >= a_X - 2 EPS for every X, so it is never pruned (a candidate is dropped only when
+// a < current best - 2 EPS), and it can only leave the top two if two others lie within the band above it --
+// which puts the third inside the band and triggers the exact walk.
 template <int NR, bool C1>
 __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     const float *__restrict__ feat, const float *__restrict__ background,
-    const float4 *__restrict__ srec, const int *__restrict__ offs,
+    const float4 *__restrict__ srec, const int *__restrict__ offs, const unsigned *__restrict__ fmax_bits,
     int channels, int batch, int h, int w, int cells_x, int cells_y, RadiiArg ra,
     float *__restrict__ out, int *__restrict__ out_ids) {
-  constexpr int kQ = 128;
-  __shared__ unsigned long long slot[4][NR][64];
-  __shared__ GatherHit queue[4][kQ];
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  GatherHit *q = queue[wave];
   long tile = (long)blockIdx.x * 4 + wave;  // (b, c, cy, cx), cx fastest
   const long tiles = (long)batch * channels * cells_y * cells_x;
   if (tile >= tiles) return;  // whole wave; no workgroup barrier below
@@ -391,161 +394,190 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   const bool valid = x < w && y < h;
   const size_t plane = ((size_t)b * channels + c) * h * w;
   const float fx = (float)x, fy = (float)y;
-  float best[NR];  // the pixel's current exact value, refreshed after every drain
-  {
-    const float bg = valid ? background[plane + (size_t)y * w + x] : 0.f;
-    const unsigned long long key = ((unsigned long long)ord_f32(bg) << 32) | 0xFFFFFFFFull;
+  const float eps = __uint_as_float(*fmax_bits) * kWeightErr, band = 2.f * eps;
+  constexpr unsigned kBg = 0xFFFFFFFFu;  // "position" of the background
+  const float bg = valid ? background[plane + (size_t)y * w + x] : 0.f;
+  float b1[NR], b2[NR], b3[NR];   // the three largest fast values seen (b1: also the pruning bound)
+  unsigned j1[NR], j2[NR];        // sorted positions (srec index) of the first two
 #pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      slot[wave][k][lane] = key;
-      best[k] = bg;
-    }
+  for (int k = 0; k < NR; ++k) {
+    b1[k] = bg;
+    j1[k] = kBg;
+    b2[k] = b3[k] = -3.0e38f;
+    j2[k] = kBg;
   }
   const float tx0 = (float)(cx * kCell), tx1 = tx0 + (kCell - 1), ty0 = (float)(cy * kCell),
               ty1 = ty0 + (kCell - 1);
-  float tile_min[NR];  // wave-uniform: smallest current best over the tile's pixels
-  int qn = 0;  // wave-uniform queue fill
-  GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_survk = 0, dg_evalk = 0, dg_hits = 0, dg_hitc = 0;)
-  // wave minimum on the order-preserving bit patterns the slots hold anyway: four DPP v_min_u32 steps and
-  // four readlanes per radius (the float butterfly was six ds_bpermute + min + canonicalising max each)
+  float tile_min[NR];  // wave-uniform: smallest b1 over the tile's pixels
+  GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_pairs = 0, dg_upd = 0, dg_amb = 0, dg_walk = 0;)
   auto refresh_tile_min = [&]() {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      unsigned m = valid ? ord_f32(best[k]) : 0xffffffffu;
+      unsigned m = valid ? ord_f32(b1[k]) : 0xffffffffu;
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x141, 0xf, 0xf, true));  // row_half_mirror
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x140, 0xf, 0xf, true));  // row_mirror
-      const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b2 = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
+      const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b2_ = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
       const unsigned c2 = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d2 = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
-      tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2), umin_u32(c2, d2)));
+      tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2_), umin_u32(c2, d2)));
     }
   };
   refresh_tile_min();
-  auto drain = [&](int first, int count) {
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < count) {
-      const GatherHit hh = q[first + lane];
-      const int k = (int)(hh.lane_k >> 6);
-      float radius = ra.radius[0];
-#pragma unroll
-      for (int i = 1; i < NR; ++i) radius = k == i ? ra.radius[i] : radius;
-      const float v = hh.f * cos_weight(__builtin_sqrtf(hh.s), radius);
-      atomicMax(&slot[wave][k][hh.lane_k & 63u], ((unsigned long long)ord_f32(v) << 32) | hh.low);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-    for (int k = 0; k < NR; ++k) best[k] = unord_f32((unsigned)(slot[wave][k][lane] >> 32));
-    refresh_tile_min();
-  };
 
   const int cell_base = b * cells_y * cells_x;
-  for (int step = 0; step <= 2 * ra.halo; ++step) {
-    // rows nearest first: 0, -1, +1, -2, +2, ... so that the best values grow early
+  // the candidate ranges of the tile: rows nearest first, the own row as own cell / left / right
+  auto row_range = [&](int step, int part, int &beg, int &end) -> bool {
     const int cyy = cy + ((step & 1) ? -((step + 1) >> 1) : (step >> 1));
-    if (cyy < 0 || cyy >= cells_y) continue;  // wave-uniform
+    if (cyy < 0 || cyy >= cells_y) return false;
     const int c_lo = cx - ra.halo > 0 ? cx - ra.halo : 0;
     const int c_hi = cx + ra.halo < cells_x - 1 ? cx + ra.halo : cells_x - 1;
-    // the tile's own row is walked own cell first, then its left and right neighbours
-    const int nparts = step == 0 ? 3 : 1;
-    for (int part = 0; part < nparts; ++part) {
     const int p_lo = step == 0 ? (part == 0 ? cx : (part == 1 ? c_lo : cx + 1)) : c_lo;
     const int p_hi = step == 0 ? (part == 0 ? cx : (part == 1 ? cx - 1 : c_hi)) : c_hi;
-    if (p_lo > p_hi) continue;
+    if (p_lo > p_hi) return false;
     const int first_cell = cell_base + cyy * cells_x + p_lo;
-    const int beg = first_cell > 0 ? offs[first_cell - 1] : 0;
-    const int end = offs[cell_base + cyy * cells_x + p_hi];
-    float4 rec_next = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (beg + lane < end) rec_next = srec[beg + lane];
-    for (int base = beg; base < end; base += 64) {
-      const int j = base + lane;
-      const float4 rec = rec_next;
-      if (j + 64 < end) rec_next = srec[j + 64];  // the next 64 candidates are in flight
-      float cpy = 0.f, cpx = 0.f, cf = 0.f;
-      unsigned clow = 0;
-      if (j < end) {
-        const int pid = __float_as_int(rec.w);
-        cpy = rec.x;
-        cpx = rec.y;
-        cf = C1 ? rec.z : feat[(size_t)pid * channels + c];
-        clow = 0xFFFFFFFEu - (unsigned)pid;
-      }
-      // Cull, 64 candidates at a time (lane = candidate): nearest pixel of the tile out of
-      // range, or even there the bound cannot reach the smallest current best of the tile.
-      unsigned long long keep[NR];
-      {
-        const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
-        const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
-        const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          const float wq = weight_bound(__builtin_fminf(smin * ra.inv_r2[k], 1.0f)) + 4e-5f;
-          const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
-          keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub >= tile_min[k]);
+    beg = first_cell > 0 ? offs[first_cell - 1] : 0;
+    end = offs[cell_base + cyy * cells_x + p_hi];
+    return beg < end;
+  };
+
+  for (int step = 0; step <= 2 * ra.halo; ++step) {
+    const int nparts = step == 0 ? 3 : 1;
+    for (int part = 0; part < nparts; ++part) {
+      int beg, end;
+      if (!row_range(step, part, beg, end)) continue;  // wave-uniform
+      float4 rec_next = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (beg + lane < end) rec_next = srec[beg + lane];
+      for (int base = beg; base < end; base += 64) {
+        const int j = base + lane;
+        const float4 rec = rec_next;
+        if (j + 64 < end) rec_next = srec[j + 64];  // the next 64 candidates are in flight
+        float cpy = 0.f, cpx = 0.f, cf = 0.f;
+        if (j < end) {
+          cpy = rec.x;
+          cpx = rec.y;
+          cf = C1 ? rec.z : feat[(size_t)__float_as_int(rec.w) * channels + c];
         }
+        // Cull, 64 candidates at a time (lane = candidate): nearest pixel of the tile out of range, or even
+        // there its value cannot come within the band of the smallest running best of the tile.
+        unsigned long long keep[NR];
+        {
+          const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
+          const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
+          const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            // weight32 decreases in u: its value at the nearest pixel (+ its error) bounds the candidate's weights
+            const float wq = weight32(__builtin_fminf(smin * ra.inv_r2[k], 1.0f)) + 4e-6f;
+            const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
+            keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub + band >= tile_min[k]);
+          }
+        }
+        unsigned long long todo = keep[0];
+#pragma unroll
+        for (int k = 1; k < NR; ++k) todo |= keep[k];
+        GDIAG(dg_batches++; dg_cand += (end - base < 64 ? end - base : 64); dg_surv += __popcll(todo);)
+        while (todo) {  // wave-uniform: candidate i broadcast to every pixel
+          const int i = __builtin_ctzll(todo);
+          todo &= todo - 1;
+          const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpy), i));
+          const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpx), i));
+          const float f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), i));
+          const float dx = fx - px, dy = fy - py;
+          const float s2 = sq2(dx, dy);
+          const unsigned pos = (unsigned)(base + i);
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
+            const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
+            const float a = f * weight32(__builtin_fminf(s2 * ra.inv_r2[k], 1.0f));
+            const bool pass = ink && a >= b1[k] - band;
+            GDIAG(dg_pairs += __popcll(__ballot(ink)); dg_upd += __popcll(__ballot(pass));)
+            if (__any(pass)) {
+              if (pass) {
+                const bool first = a > b1[k], second = !first && a > b2[k], third = !first && !second && a > b3[k];
+                b3[k] = first || second ? b2[k] : (third ? a : b3[k]);
+                b2[k] = first ? b1[k] : (second ? a : b2[k]);
+                j2[k] = first ? j1[k] : (second ? pos : j2[k]);
+                b1[k] = first ? a : b1[k];
+                j1[k] = first ? pos : j1[k];
+              }
+            }
+          }
+        }
+        refresh_tile_min();
       }
-      unsigned long long todo = keep[0];
+    }
+  }
+
+  // ---- exact values: the winner, the runner-up when it is inside the band, an exact walk when the third is too
+  auto exact_of = [&](unsigned pos, float radius, float s_max, float &v, unsigned &low) {
+    // value and tie key (0xFFFFFFFE - id: larger = lower id) of the candidate at sorted position `pos`
+    const float4 rec = srec[pos];
+    const int pid = __float_as_int(rec.w);
+    const float f = C1 ? rec.z : feat[(size_t)pid * channels + c];
+    const float s2 = sq2(fx - rec.y, fy - rec.x);
+    (void)s_max;
+    v = f * cos_weight(__builtin_sqrtf(s2), radius);
+    low = 0xFFFFFFFEu - (unsigned)pid;
+  };
+  const size_t image = (size_t)batch * channels * h * w;  // one output tensor per radius
 #pragma unroll
-      for (int k = 1; k < NR; ++k) todo |= keep[k];
-      GDIAG(dg_batches++; dg_cand += (end - base < 64 ? end - base : 64); dg_surv += __popcll(todo);
-            for (int k = 0; k < NR; ++k) dg_survk += __popcll(keep[k]);)
-      while (todo) {  // wave-uniform: candidate i broadcast to every pixel
-        const int i = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        const float py = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpy), i));
-        const float px = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cpx), i));
-        const float dx = fx - px, dy = fy - py;
-        const float s2 = sq2(dx, dy);
-        const float f = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cf), i));
-        // feature * weight <= f * max(w +- 2e-5, 0): the slack goes up for f >= 0, down otherwise
-#pragma unroll
-        for (int k = 0; k < NR; ++k) {
-          if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
-          const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
-          // feature * weight <= f * bound for f >= 0; a negative feature times a weight >= 0 is <= 0
-          const float ub = f >= 0.f ? f * (weight_bound(__builtin_fminf(s2 * ra.inv_r2[k], 1.0f)) + 2e-5f) : 0.f;
-          const bool pass = ink && ub >= best[k];  // can still reach (or tie with) the best
-          const unsigned long long m = __ballot(pass);
-          GDIAG(dg_evalk++; dg_hits += __popcll(m); dg_hitc += m ? 1 : 0;)
-          if (m) {
-            if (pass)
-              q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] =
-                  GatherHit{(unsigned)lane | ((unsigned)k << 6), s2, f,
-                            (unsigned)__builtin_amdgcn_readlane((int)clow, i)};
-            qn += __popcll(m);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            if (qn >= 64) {
-              qn -= 64;
-              drain(qn, 64);
+  for (int k = 0; k < NR; ++k) {
+    float best_v = bg;          // the reference replaces only on strictly greater: the background wins ties
+    unsigned best_low = kBg;    // kBg = no point
+    const bool walk = valid && b3[k] >= b1[k] - band;
+    const bool amb = valid && !walk && b2[k] >= b1[k] - band;
+    GDIAG(dg_amb += __popcll(__ballot(amb)); dg_walk += __popcll(__ballot(walk));)
+    if (valid && !walk) {
+      auto consider = [&](unsigned pos) {
+        if (pos == kBg) return;
+        float v;
+        unsigned low;
+        exact_of(pos, ra.radius[k], ra.s_max[k], v, low);
+        if (v > best_v || (v == best_v && best_low != kBg && low > best_low)) {
+          best_v = v;
+          best_low = low;
+        }
+      };
+      consider(j1[k]);
+      if (amb) consider(j2[k]);
+    }
+    if (__any(walk)) {  // rare: three or more candidates inside the band -- settle the pixel exactly
+      for (int step = 0; step <= 2 * ra.halo; ++step) {
+        const int nparts = step == 0 ? 3 : 1;
+        for (int part = 0; part < nparts; ++part) {
+          int beg, end;
+          if (!row_range(step, part, beg, end)) continue;
+          for (int pos = beg; pos < end; ++pos) {
+            const float4 rec = srec[pos];  // wave-uniform address
+            const float s2 = sq2(fx - rec.y, fy - rec.x);
+            if (walk && s2 <= ra.s_max[k]) {
+              const int pid = __float_as_int(rec.w);
+              const float f = C1 ? rec.z : feat[(size_t)pid * channels + c];
+              const float v = f * cos_weight(__builtin_sqrtf(s2), ra.radius[k]);
+              const unsigned low = 0xFFFFFFFEu - (unsigned)pid;
+              if (v > best_v || (v == best_v && best_low != kBg && low > best_low)) {
+                best_v = v;
+                best_low = low;
+              }
             }
           }
         }
       }
     }
-    if (step <= SN_P2I_DRAIN_STEPS && qn > 0) {  // near cells: establish the bests early
-      drain(0, qn);
-      qn = 0;
-    }
+    if (valid) {
+      const size_t e = k * image + plane + (size_t)y * w + x;
+      out[e] = best_v;
+      out_ids[e] = best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low);
     }
   }
-  if (qn > 0) drain(0, qn);
   GDIAG(if (lane == 0) {
     atomicAdd(&g_gather_diag[0], 1ull); atomicAdd(&g_gather_diag[1], (unsigned long long)dg_batches);
     atomicAdd(&g_gather_diag[2], (unsigned long long)dg_cand); atomicAdd(&g_gather_diag[3], (unsigned long long)dg_surv);
-    atomicAdd(&g_gather_diag[4], (unsigned long long)dg_survk); atomicAdd(&g_gather_diag[5], (unsigned long long)dg_evalk);
-    atomicAdd(&g_gather_diag[6], (unsigned long long)dg_hits); atomicAdd(&g_gather_diag[7], (unsigned long long)dg_hitc);
+    atomicAdd(&g_gather_diag[4], (unsigned long long)dg_pairs); atomicAdd(&g_gather_diag[5], (unsigned long long)dg_upd);
+    atomicAdd(&g_gather_diag[6], (unsigned long long)dg_amb); atomicAdd(&g_gather_diag[7], (unsigned long long)dg_walk);
   })
-  if (valid) {
-    const size_t image = (size_t)batch * channels * h * w;  // one output tensor per radius
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-      const unsigned long long key = slot[wave][k][lane];
-      const unsigned lw = (unsigned)key;
-      const size_t e = k * image + plane + (size_t)y * w + x;
-      out[e] = unord_f32((unsigned)(key >> 32));
-      out_ids[e] = lw == 0xFFFFFFFFu ? -1 : (int)(0xFFFFFFFEu - lw);
-    }
-  }
 }
 
 __global__ __launch_bounds__(256) void p2i_max_finalize_kernel(
@@ -922,7 +954,7 @@ constexpr float kTileMaxRadius = 16.f;  // larger kernels use the global scatter
 
 size_t tile_workspace_bytes(int npoints, int batch, int h, int w) {
   const size_t cells = (size_t)batch * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);
-  return 2 * sn::align_up(cells * 4, 256) + (size_t)npoints * 16;
+  return 256 + 2 * sn::align_up(cells * 4, 256) + (size_t)npoints * 16;
 }
 
 // largest fp32 s with sqrtf(s) <= radius, on the host (IEEE sqrtf is correctly rounded there too)
@@ -965,6 +997,8 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
   const long tiles = cells * channels;
   SN_REQUIRE(tiles / 4 + 1 < (1L << 31), "%s: too many tiles", fn);
   char *wp = static_cast<char *>(workspace);
+  unsigned *fmax_bits = reinterpret_cast<unsigned *>(wp); wp += 256;   // max |feature| (bits), for the error band
+  SN_HIP(hipMemsetAsync(fmax_bits, 0, 4, s));
   int *counts = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   int *offs = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   float4 *srec = reinterpret_cast<float4 *>(wp);
@@ -974,7 +1008,7 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
                                                              h, w, cells_x, cells_y);
   p2i_bin_scan_kernel<<<batch, 1024, 0, s>>>(counts, offs, cells_x * cells_y);
   if (npoints > 0)
-    p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, feat, batch_inds, offs, srec,
+    p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, feat, batch_inds, offs, srec, fmax_bits,
                                                                npoints, channels, batch, h, w, cells_x,
                                                                cells_y);
   const int blocks = (int)((tiles + 3) / 4);
@@ -982,10 +1016,10 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
   do {                                                                                        \
     if (channels == 1)                                                                        \
       p2i_gather_max_kernel<NR, true><<<blocks, 256, 0, s>>>(feat, background, srec, offs,      \
-          channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);                         \
+          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);              \
     else                                                                                      \
       p2i_gather_max_kernel<NR, false><<<blocks, 256, 0, s>>>(feat, background, srec, offs,     \
-          channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);                         \
+          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);              \
   } while (0)
   if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
   switch (nradii) {
