@@ -41,8 +41,8 @@ while time.time() < t_end:
     r1, r2, i1, i2 = oracle.chamfer_forward(x, y, mt=True)
     rg1, rg2 = oracle.chamfer_backward(x, y, g1, g2, i1, i2)
     check("chamfer", np.array_equal(d1.detach().cpu().numpy(), r1) and np.array_equal(d2.detach().cpu().numpy(), r2)
-          and np.allclose(xt.grad.cpu().numpy(), rg1, rtol=1e-5, atol=1e-6)
-          and np.allclose(yt.grad.cpu().numpy(), rg2, rtol=1e-5, atol=1e-6), dict(b=b, n=n, m=m))
+          and np.array_equal(xt.grad.cpu().numpy(), rg1)
+          and np.array_equal(yt.grad.cpu().numpy(), rg2), dict(b=b, n=n, m=m))
     # ---- EMD forward + backward (bit-exact: single writer per element)
     b, n = int(rng.integers(1, 4)), int(rng.choice([1024, 2048]))
     x, y = rng.random((b, n, 3), dtype=np.float32), rng.random((b, n, 3), dtype=np.float32)
