@@ -422,12 +422,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    shared = os.environ.get("BENCH_DEBUG_SHARED_GPU") == "1"   # debugging aid: N ranks on ONE GPU over gloo
+    if shared:
+        local = 0
     torch.cuda.set_device(local)   # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
     if B % world:
         raise SystemExit(f"the strong split shards {B} clouds: world size {world} must divide it")
 
