@@ -562,6 +562,9 @@ struct BidCtx {
   const f4 *ms;      // MFMA operand stream of this cloud
   const float *sbb;  // block boxes of this cloud
   BidOut A;
+#ifdef SN_BID_STAMPS
+  long long *stamps;  // experiment build: per-wave time per part of bid_group (100 MHz ticks), or nullptr
+#endif
 };
 
 // One group of 64 bidders, seen by one of its S segment-waves.
@@ -576,6 +579,15 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
   const float2 *pkc = c.pkc;
   Top2 top = {-1e9f, -1e9f, -1, -1};
   int j = 0;
+#ifdef SN_BID_STAMPS
+  long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tk = (long long)__builtin_amdgcn_s_memrealtime();
+#define STAMP(i) { const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); st[i] += now_ - tk; tk = now_; }
+#define COUNT(i) st[i] += 1;
+#else
+#define STAMP(i)
+#define COUNT(i)
+#endif
   if (grp < ngroups) {  // wave-uniform
     j = ldc(&lst[active ? u : grp * 64]);
     float blo[4][3], bhi[4][3];
@@ -639,8 +651,12 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       bool pend = on && filter_pass(sq, filter_target(pq.x), filter_thr(T.cm[cc]));
       float d = 0.f;
       if (pend) d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pq.x);
+#ifdef SN_BID_STAMPS
+      st[12] += __popcll(__ballot(pend));
+#endif
       volatile int *own = T.owner;
       while (__any(pend)) {
+        COUNT(13)
         asm volatile("" ::: "memory");
         if (pend) own[cc] = lane;
         if (pend && own[cc] == lane) {
@@ -667,6 +683,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       }
     };
     refresh_reach();
+    STAMP(0)
     const f4 *ms = c.ms + lane;
     const float *sbb = c.sbb;
     auto worth = [&](const f4 lo4, const f4 hi4) {
@@ -699,33 +716,51 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       }
       unsigned gmask = quad_mask(mine ? worth(box_lo, box_hi) : 0u);
       unsigned long long todo = __ballot(gmask != 0u && (lane & 3) == 0);
+      // The operand of a visit is ALWAYS the one requested during the previous visit, and every visit requests
+      // exactly one (the last one asks for its own again): with a conditional request hipcc has to wait for
+      // "all loads" in front of the MFMAs, which serialised every visit behind the next operand's L2 latency.
       f4 a_next = {0.f, 0.f, 0.f, 0.f};
-      int next_sb = -1;
+      int next_sb = 0;
+      if (todo) {
+        next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
+        a_next = ms[(size_t)next_sb * 64];
+      }
+      STAMP(1)
       while (todo) {
+        COUNT(6)
         const int tl = __builtin_ctzll(todo);
         const int sb = ((t0 + tl) >> 2) * S + seg;
         todo &= todo - 1;
         const int kb = sb * 64;
-        const f4 a = sb == next_sb ? a_next : ms[(size_t)sb * 64];
-        if (todo) {
-          next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
-          a_next = ms[(size_t)next_sb * 64];
-        }
+        const f4 a = a_next;
+        next_sb = todo ? ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg : sb;
+        a_next = ms[(size_t)next_sb * 64];
+#ifdef SN_BID_STAMPS
+        STAMP(2)
+        if (todo) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        STAMP(5)
+#endif
         bool drained = false;
         const unsigned gm = (unsigned)__builtin_amdgcn_readlane((int)gmask, tl);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           if (!(gm & (0x1111u << g))) continue;
+          COUNT(8)
+          // all four blocks of the superblock once the subgroup reaches any of them: a skipped MFMA costs
+          // a branch and four moves of "far" into its result registers on the vector ALU, which is the busy
+          // unit here -- the matrix pipe is not (a block out of reach cannot produce a hit that matters)
           const f4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f4 far = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};
-          const f4 d0 = (gm >> g) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0) : far;
-          const f4 d1 = (gm >> (4 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0) : far;
-          const f4 d2 = (gm >> (8 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0) : far;
-          const f4 d3 = (gm >> (12 + g)) & 1u ? __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0) : far;
+          const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
+          const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
+          const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
+          const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
           if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
             unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
                           hits4(d3, thr[g], 12);
+            COUNT(9)
+            STAMP(2)
             while (__any(hm != 0)) {
+              COUNT(10)
               const bool has = hm != 0;
               const int i = has ? __builtin_ctz(hm) : 0;
               hm &= hm - 1;
@@ -737,12 +772,19 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
                 T.queue[pos] = (unsigned)(kb + 16 * (i >> 2) + 4 * row + (i & 3)) |
                                ((unsigned)(16 * g + col) << 20);
               qcount += __popcll(bal);
+#ifdef SN_BID_STAMPS
+              st[11] += __popcll(bal);
+#endif
               while (qcount >= 64) {
                 qcount -= 64;
+                STAMP(14)
                 batch(qcount, 64);
+                STAMP(3)
+                COUNT(7)
                 drained = true;
               }
             }
+            STAMP(14)
           }
         }
         if (drained) {
@@ -754,11 +796,20 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
             const bool left = (todo >> (lane & ~3)) & 1ull;
             gmask = quad_mask(left ? worth(box_lo, box_hi) : 0u);
             todo = __ballot(gmask != 0u && (lane & 3) == 0);
+            if (todo) {  // the tightened reach may have dropped the superblock whose operand is on its way
+              const int nsb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
+              if (nsb != next_sb) {
+                next_sb = nsb;
+                a_next = ms[(size_t)next_sb * 64];
+              }
+            }
           }
         }
+        STAMP(2)
       }
     }
     if (qcount > 0) batch(0, qcount);
+    STAMP(4)
     top = Top2{T.best[lane], T.better[lane], T.bi[lane], T.bi2[lane]};
   }
   bool emit = seg == 0;
@@ -784,6 +835,11 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
     }
   }
   if (emit && active) emit_bid(c.A, c.o, j, top, c.eps);
+#ifdef SN_BID_STAMPS
+  STAMP(4)
+  if (c.stamps && lane == 0)
+    for (int i = 0; i < 16; ++i) c.stamps[i] += st[i];
+#endif
 }
 
 struct AuctionArgs {
@@ -976,6 +1032,9 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
         while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
         const int gpb = kBidWaves / S;
         const int seg = wave & (S - 1), gslot = wave / S;
+#ifdef SN_BID_STAMPS
+        c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
+#endif
         for (int q0 = 0; q0 < ngroups; q0 += gpb) {
           bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
           if (q0 + gpb < ngroups) __syncthreads();

@@ -50,3 +50,14 @@ if os.environ.get("SN_EMD_DIAG"):
             tail = t[10:]
             print("  tail mean per iteration:", {names[p]: round(float(tail[:, :, p].mean()), 1) for p in range(8)},
                   "sum", round(float(tail.mean(1).sum(1).mean()), 1))
+        if os.environ.get("BID_STAMPS"):   # a library built with -DSN_BID_STAMPS (tools/build_variant.sh)
+            w = v[16 + 3200:16 + 3200 + 3 * 16 * 16].reshape(3, 16, 16).astype(float)
+            names2 = ["setup", "boxes", "visits (filter)", "drain batches", "final+merge", "operand wait", "#visits", "#drains",
+                      "#g-blocks", "#g-blocks hit", "#enqueue rounds", "#hits", "#exact evals", "#election rounds", "enqueue", "-"]
+            per_it = 40.0
+            print("bid_group, tail iterations (it >= 10), per wave and iteration; us or counts (mean over 48 waves / max wave):")
+            for i, n_ in enumerate(names2):
+                sc = 100.0 if (i < 6 or i == 14) else 1.0
+                print(f"  {n_:16s} {w[:, :, i].mean() / sc / per_it:7.2f} / {w[:, :, i].max() / sc / per_it:7.2f}")
+            tot = (w[:, :, :6].sum(2) + w[:, :, 14]) / 100.0 / per_it
+            print("  total per wave: mean", round(float(tot.mean()), 2), "max", round(float(tot.max()), 2), "per-wg max", np.round(tot.max(1), 1))
