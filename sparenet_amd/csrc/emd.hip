@@ -206,7 +206,8 @@ struct EmdWs {
   float *max_inc;
   int *max_idx;  // GetMax's winner per target; PERSISTS across iterations like the reference's tensor
   int *win;      // this iteration's in-window winner per target (-1: nobody was in the window)
-  int *list[2];
+  int *list[1];  // the unassigned bidders of the iteration, per workgroup in its own rank range
+  float *prt;    // [B, n/64, 16, 4] prices by stream position, transposed for the coarse filter (see bid_group)
   int *bins[2];  // [B, 64] ping-pong: flagged (= unassigned) bidders per 1/64 of the rank range
   f4 *t4s;       // [B, n] by stream position p: {x, y, z, A'} of target tperm[p]
   float2 *pk;    // [B, n] by stream position: {price, target index bits}
@@ -241,6 +242,7 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
     ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
     ws.flags[e] = 1;  // every bidder starts flagged (= unassigned)
+    ws.prt[e] = 0.f;
     {  // stream position p of this cloud holds target k = tperm[p]
       const long bb = e / n;
       const int p = (int)(e - bb * n);
@@ -336,10 +338,10 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
     lo = lo < 0 ? 0 : (lo > n - 16 ? n - 16 : lo);
     float s1 = 3e38f, s2 = 3e38f;
     int k1 = -1, k2 = -1;
-    for (int p = lo; p < lo + 16; ++p) {
-      const int k = ws.tperm[bb * n + p];
-      const float *t = xyz2 + (bb * n + k) * 3;
-      const float dx = t[0] - x, dy = t[1] - y, dz = t[2] - z;
+    for (int p = lo; p < lo + 16; ++p) {  // the prepared stream: one 16-byte record per position, no second gather
+      const f4 t = ws.t4s[bb * n + p];
+      const int k = __float_as_int(ws.pk[bb * n + p].y);
+      const float dx = t.x - x, dy = t.y - y, dz = t.z - z;
       const float sq = (dx * dx + dy * dy) + dz * dz;
       if (sq < s1) {
         s2 = s1;
@@ -560,6 +562,7 @@ struct BidCtx {
   const float2 *pkc;
   const int *rk2;
   const f4 *ms;      // MFMA operand stream of this cloud
+  const f4 *prt;     // prices of this cloud, transposed (plain loads on purpose: see below); nullptr: not used
   const float *sbb;  // block boxes of this cloud
   BidOut A;
 #ifdef SN_BID_STAMPS
@@ -627,17 +630,47 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       T.bi[lane] = -1;
       T.bi2[lane] = -1;
     }
-    float thr[4], base[4], bop[4];
+    // Level 1 with the target's own price (c.prt != nullptr: eps >= 0 and not the first iteration).  With
+    // a_k = A'_k - 3 and gamma_j = c'_j - 3 (both small: the squares below do not cancel),
+    //   s <= (A'_k - c'_j)^2   <=>   u_kj - a_k^2 + 2 a_k gamma_j  <=  gamma_j^2 - |x_j|^2,
+    // and the left side is the first MFMA's result carried through a SECOND one with rows (-a_k^2, 2 a_k, 0, 0)
+    // and columns (1, gamma_j, 0, 0).  The rows come from `prt`, the prices by stream position written by Assign
+    // and read here with PLAIN loads: a stale line holds an earlier -- lower -- price of the same target
+    // (prices only rise for eps >= 0), i.e. a larger A'_k, which only lets more pairs through.  The squared form
+    // forgets the sign of A'_k - c'_j: a negative one passes spuriously and is rejected at level 2; a bidder
+    // for whom even A'max - c'_j is negative gets the threshold -3e38.  Slack: eight fmaf roundings of partial
+    // sums <= 2 (|t|^2 + |x|^2) + (|a| + |gamma|)^2 with |a| <= |gamma| for every pair level 2 can pass, the
+    // rounding of a_k, a_k^2, gamma_j^2 and of level 2's own r |r|: 2^-17 (max|t|^2 + |x|^2) + 2^-16 gamma^2
+    // covers them four times over.
+    const bool up = c.prt != nullptr;  // wave-uniform
+    float thr[4], bop[4], bop2[4];
+    auto set_thresholds = [&]() {  // at the start and after every drain (rare with prices in level 1)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma clang fp contract(off)
+        const int cc = 16 * g + col;
+        const float x = T.x[cc], y = T.y[cc], z = T.z[cc];
+        const float xx = (x * x + y * y) + z * z;
+        const float base = 7.62939453125e-06f * (tmax + xx) - xx;  // 2^-17: see above (2^-18 would do without prices)
+        const float cmv = T.cm[cc];
+        if (!up) {
+          thr[g] = coarse_threshold(cmv, base, a_max);
+          bop2[g] = 0.f;
+        } else {
+          const float ct = filter_thr(cmv);
+          const bool open = a_max - ct >= 0.f;  // false for idle lanes (cm = 3e38) as well
+          const float gam = ct - 3.0f;
+          thr[g] = open ? __builtin_fmaf(gam * gam, 1.0000152587890625f, base) : -3.0e38f;
+          bop2[g] = row == 0 ? 1.0f : (row == 1 && open ? gam : 0.f);
+        }
+      }
+    };
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-#pragma clang fp contract(off)
       const int cc = 16 * g + col;
-      const float x = T.x[cc], y = T.y[cc], z = T.z[cc];
-      const float xx = (x * x + y * y) + z * z;
-      base[g] = 3.814697265625e-06f * (tmax + xx) - xx;
-      thr[g] = coarse_threshold(T.cm[cc], base[g], a_max);
-      bop[g] = row == 0 ? x : (row == 1 ? y : (row == 2 ? z : 1.0f));
+      bop[g] = row == 0 ? T.x[cc] : (row == 1 ? T.y[cc] : (row == 2 ? T.z[cc] : 1.0f));
     }
+    set_thresholds();
     int qcount = 0;
 
     auto batch = [&](int first, int cnt) {
@@ -685,6 +718,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
     refresh_reach();
     STAMP(0)
     const f4 *ms = c.ms + lane;
+    const f4 *prt = c.prt + col;
     const float *sbb = c.sbb;
     auto worth = [&](const f4 lo4, const f4 hi4) {
       unsigned m = 0;
@@ -719,11 +753,12 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       // The operand of a visit is ALWAYS the one requested during the previous visit, and every visit requests
       // exactly one (the last one asks for its own again): with a conditional request hipcc has to wait for
       // "all loads" in front of the MFMAs, which serialised every visit behind the next operand's L2 latency.
-      f4 a_next = {0.f, 0.f, 0.f, 0.f};
+      f4 a_next = {0.f, 0.f, 0.f, 0.f}, p_next = {0.f, 0.f, 0.f, 0.f};
       int next_sb = 0;
       if (todo) {
         next_sb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
         a_next = ms[(size_t)next_sb * 64];
+        if (up) p_next = prt[(size_t)next_sb * 16];
       }
       STAMP(1)
       while (todo) {
@@ -732,9 +767,19 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
         const int sb = ((t0 + tl) >> 2) * S + seg;
         todo &= todo - 1;
         const int kb = sb * 64;
-        const f4 a = a_next;
+        const f4 a = a_next, pr = p_next;
         next_sb = todo ? ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg : sb;
         a_next = ms[(size_t)next_sb * 64];
+        f4 a2 = {0.f, 0.f, 0.f, 0.f};
+        if (up) {
+          p_next = prt[(size_t)next_sb * 16];
+          const float t0_ = filter_target(pr.x) - 3.0f, t1_ = filter_target(pr.y) - 3.0f;
+          const float t2_ = filter_target(pr.z) - 3.0f, t3_ = filter_target(pr.w) - 3.0f;
+          a2.x = row == 0 ? -(t0_ * t0_) : (row == 1 ? 2.f * t0_ : 0.f);
+          a2.y = row == 0 ? -(t1_ * t1_) : (row == 1 ? 2.f * t1_ : 0.f);
+          a2.z = row == 0 ? -(t2_ * t2_) : (row == 1 ? 2.f * t2_ : 0.f);
+          a2.w = row == 0 ? -(t3_ * t3_) : (row == 1 ? 2.f * t3_ : 0.f);
+        }
 #ifdef SN_BID_STAMPS
         STAMP(2)
         if (todo) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -750,10 +795,16 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
           // a branch and four moves of "far" into its result registers on the vector ALU, which is the busy
           // unit here -- the matrix pipe is not (a block out of reach cannot produce a hit that matters)
           const f4 zero = {0.f, 0.f, 0.f, 0.f};
-          const f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
-          const f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
-          const f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
-          const f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+          f4 d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bop[g], zero, 0, 0, 0);
+          f4 d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bop[g], zero, 0, 0, 0);
+          f4 d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bop[g], zero, 0, 0, 0);
+          f4 d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bop[g], zero, 0, 0, 0);
+          if (up) {
+            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bop2[g], d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bop2[g], d1, 0, 0, 0);
+            d2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, bop2[g], d2, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bop2[g], d3, 0, 0, 0);
+          }
           if (__builtin_expect(__any(min16(d0, d1, d2, d3) <= thr[g]), 0)) {
             unsigned hm = hits4(d0, thr[g], 0) | hits4(d1, thr[g], 4) | hits4(d2, thr[g], 8) |
                           hits4(d3, thr[g], 12);
@@ -788,19 +839,23 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
           }
         }
         if (drained) {
-#pragma unroll
-          for (int gg = 0; gg < 4; ++gg)
-            thr[gg] = coarse_threshold(T.cm[16 * gg + col], base[gg], a_max);
+          set_thresholds();
           refresh_reach();
-          if (todo) {
+          if (todo) {  // the lane's block box again (not kept in registers across the visits: drains are rare)
             const bool left = (todo >> (lane & ~3)) & 1ull;
-            gmask = quad_mask(left ? worth(box_lo, box_hi) : 0u);
+            f4 lo4 = {0.f, 0.f, 0.f, 0.f}, hi4 = {0.f, 0.f, 0.f, 0.f};
+            if (left) {
+              lo4 = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8);
+              hi4 = *reinterpret_cast<const f4 *>(sbb + (size_t)(sbl * 4 + (task & 3)) * 8 + 4);
+            }
+            gmask = quad_mask(left ? worth(lo4, hi4) : 0u);
             todo = __ballot(gmask != 0u && (lane & 3) == 0);
             if (todo) {  // the tightened reach may have dropped the superblock whose operand is on its way
               const int nsb = ((t0 + __builtin_ctzll(todo)) >> 2) * S + seg;
               if (nsb != next_sb) {
                 next_sb = nsb;
                 a_next = ms[(size_t)next_sb * 64];
+                if (up) p_next = prt[(size_t)next_sb * 16];
               }
             }
           }
@@ -1025,6 +1080,9 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
       // ---- bid
       {
         c.geom = TieGeom{n, 1024 / ((U + block_cnt - 1) / block_cnt)};
+        // prices in level 1 once the bidders are sparse (measured at n = 16384: from ~900 unassigned bidders
+        // per cloud on the second MFMA pays for itself through fewer hits; earlier it costs 10-20 %)
+        c.prt = (a.eps >= 0.f && it > 0 && U * 16 <= n) ? reinterpret_cast<const f4 *>(a.ws.prt + o) : nullptr;
         const float price_floor = a.eps < 0.f ? a.eps * (float)it : 0.f;
         c.a_max = filter_target(price_floor) + 9.5367431640625e-07f;
         const int ngroups = (Um + 63) >> 6;
@@ -1094,6 +1152,7 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
             stc(&price[o + tgt], np);
             const int pos = a.ws.rank2[o + tgt];  // the bid phase reads the price by stream position
             stc(reinterpret_cast<float *>(a.ws.pk + o + pos), np);
+            stc(a.ws.prt + o + ((pos >> 6) * 64 + (pos & 15) * 4 + ((pos >> 4) & 3)), np);  // [sb][c][q]
             stc(&bo.max_inc[o + tgt], -1e9f);
           } else {
             raise(a.ws.rank1[o + j]);  // lost: bids again
@@ -1169,7 +1228,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.max_idx = reinterpret_cast<int *>(p); p += arr;
   ws.win = reinterpret_cast<int *>(p); p += arr;
   ws.list[0] = reinterpret_cast<int *>(p); p += arr;
-  ws.list[1] = reinterpret_cast<int *>(p); p += arr;
+  ws.prt = reinterpret_cast<float *>(p); p += arr;
   ws.bins[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
   ws.bins[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
   ws.t4s = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
