@@ -184,10 +184,10 @@ __device__ __forceinline__ int2 ldc2(const int *p) {  // 8-byte aligned pair
 }
 
 // Prepared target data per cloud, all in Morton order (stream position p holds target tperm[p]):
-//  * t4s[p] = {x, y, z, A'_k}, A'_k = filter_target(price_k), and pk[p] = {price_k, k}: what
-//    the precise filter and the exact path read, both addressed by the stream position of a hit
-//    (one round trip).  Written by emd_init_kernel, A' and the price refreshed by
-//    emd_assign_kernel for the targets whose price changed (rank2[k] = p).
+//  * t4s[p] = {x, y, z, k} (constant) and pk[p] = {price_k, k}: what the precise filter and the exact path
+//    read, both addressed by the stream position of a hit (one round trip).  Written by emd_init_kernel,
+//    the price refreshed by the Assign phase for the targets whose price changed (rank2[k] = p); the same
+//    price goes to prt, the transposed copy the coarse filter reads.
 //  * mstream: the MFMA A-operand of the coarse filter, price independent (written once).
 //    u_kj = |t_k|^2 - 2 t_k . x_j is a [targets x 4] . [4 x bidders] product with rows
 //    (-2x, -2y, -2z, |t|^2) and columns (x, y, z, 1).  v_mfma_f32_16x16x4_f32 takes ONE float
@@ -209,7 +209,7 @@ struct EmdWs {
   int *list[1];  // the unassigned bidders of the iteration, per workgroup in its own rank range
   float *prt;    // [B, n/64, 16, 4] prices by stream position, transposed for the coarse filter (see bid_group)
   int *bins[2];  // [B, 64] ping-pong: flagged (= unassigned) bidders per 1/64 of the rank range
-  f4 *t4s;       // [B, n] by stream position p: {x, y, z, A'} of target tperm[p]
+  f4 *t4s;       // [B, n] by stream position p: {x, y, z, index bits} of target tperm[p] (constant in the launch)
   float2 *pk;    // [B, n] by stream position: {price, target index bits}
   int *rank2;    // [B, n] target index -> stream position
   f4 *mstream;   // [B, n/64, 64], targets in Morton order (position p holds target tperm[p])
@@ -249,7 +249,7 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
       const int k = ws.tperm[e];
       const float *t = xyz2 + (bb * n + k) * 3;
       const float x = t[0], y = t[1], z = t[2];
-      ws.t4s[e] = f4{x, y, z, filter_target(0.f)};
+      ws.t4s[e] = f4{x, y, z, __int_as_float(k)};
       ws.pk[e] = make_float2(0.f, __int_as_float(k));
       ws.rank2[bb * n + k] = p;
       const float tt = (x * x + y * y) + z * z;
@@ -322,8 +322,11 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
   const long total = (long)B * n;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (long)gridDim.x * blockDim.x) {
+    // threads walk the bidders in sorted (Hilbert) order: neighbouring threads then read overlapping windows
+    // of the target stream out of the L1 instead of 384 scattered bytes each
     const long bb = e / n;
-    const float x = xyz1[e * 3 + 0], y = xyz1[e * 3 + 1], z = xyz1[e * 3 + 2];
+    const long je = bb * n + ws.perm1[e];
+    const float x = xyz1[je * 3 + 0], y = xyz1[je * 3 + 1], z = xyz1[je * 3 + 2];
     const float *box = ws.bbox + bb * 6;
     unsigned q[3];
     const float v[3] = {x, y, z};
@@ -338,9 +341,10 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
     lo = lo < 0 ? 0 : (lo > n - 16 ? n - 16 : lo);
     float s1 = 3e38f, s2 = 3e38f;
     int k1 = -1, k2 = -1;
+#pragma unroll
     for (int p = lo; p < lo + 16; ++p) {  // the prepared stream: one 16-byte record per position, no second gather
       const f4 t = ws.t4s[bb * n + p];
-      const int k = __float_as_int(ws.pk[bb * n + p].y);
+      const int k = __float_as_int(t.w);
       const float dx = t.x - x, dy = t.y - y, dz = t.z - z;
       const float sq = (dx * dx + dy * dy) + dz * dz;
       if (sq < s1) {
@@ -353,8 +357,8 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
         k2 = k;
       }
     }
-    ws.bid[e] = k1;
-    ws.bid2[e] = k2;
+    ws.bid[je] = k1;
+    ws.bid2[je] = k2;
   }
 }
 
