@@ -9,7 +9,7 @@ python - <<PY
 import csv
 rows = list(csv.reader(open("$f")))
 print(f"{'calls':>6} {'total_ms':>9} {'avg_us':>9} {'%':>6}  name")
-for r in rows[1:13]:
+for r in rows[1:int(__import__("os").environ.get("KTOP", "13"))]:
     print(f"{r[1]:>6} {float(r[2])/1e6:9.3f} {float(r[3])/1e3:9.1f} {float(r[4]):6.2f}  {r[0][:90]}")
 PY
 rm -rf gpurun_out/kst
