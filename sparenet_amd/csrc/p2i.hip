@@ -265,7 +265,8 @@ __device__ __forceinline__ int cell_of_point(float py, float px, int h, int w, i
 
 __global__ __launch_bounds__(256) void p2i_bin_count_kernel(
     const float *__restrict__ points, const int *__restrict__ batch_inds, int *__restrict__ offs,
-    int npoints, int batch, int h, int w, int cells_x, int cells_y) {
+    int npoints, int batch, int h, int w, int cells_x, int cells_y, const unsigned *__restrict__ need) {
+  if (*need == 0u) return;  // p2i_bin_grouped_kernel has binned everything
   for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
        pid += gridDim.x * blockDim.x) {
     const int b = batch_inds[pid];
@@ -280,9 +281,11 @@ __global__ __launch_bounds__(256) void p2i_bin_count_kernel(
 // alias counts (other workgroups still read them).
 __global__ __launch_bounds__(1024) void p2i_bin_scan_kernel(const int *__restrict__ counts,
                                                             int *__restrict__ offs_out,
-                                                            int cells_per_image) {
+                                                            int cells_per_image,
+                                                            const unsigned *__restrict__ need) {
   __shared__ int wsum[16];
   __shared__ int carry;
+  if (*need == 0u) return;
   const int tid = threadIdx.x, b = blockIdx.x;
   int before = 0;
   for (long i = tid; i < (long)b * cells_per_image; i += 1024) before += counts[i];
@@ -322,7 +325,8 @@ __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
     const float *__restrict__ points, const float *__restrict__ feat,
     const int *__restrict__ batch_inds, int *__restrict__ offs, float4 *__restrict__ srec,
     unsigned *__restrict__ fmax_bits, int npoints, int channels, int batch, int h, int w, int cells_x,
-    int cells_y) {
+    int cells_y, const unsigned *__restrict__ need) {
+  if (*need == 0u) return;
   float fm = 0.f;  // largest |feature| of the binned points: scales the error bound of the gather's fast path
   for (int pid = blockIdx.x * blockDim.x + threadIdx.x; pid < npoints;
        pid += gridDim.x * blockDim.x) {
@@ -338,6 +342,77 @@ __global__ __launch_bounds__(256) void p2i_bin_scatter_kernel(
   for (int m = 1; m < 64; m <<= 1) fm = __builtin_fmaxf(fm, __shfl_xor(fm, m));
   // non-negative floats order like their bit patterns; the read first keeps 65k waves off one address
   if ((threadIdx.x & 63) == 0 && __float_as_uint(fm) > *reinterpret_cast<volatile unsigned *>(fmax_bits))
+    atomicMax(fmax_bits, __float_as_uint(fm));
+}
+
+// The common layout -- image b owns the points [b * ppi, (b + 1) * ppi), which is what ComputeDepthMaps passes --
+// binned by ONE workgroup per image with its counters in LDS: count, scan and scatter in one launch without a
+// single global atomic (the three generic kernels above: 4.2 M global atomics each way for a sweep of 8 views,
+// 0.32 ms; this one reads the points twice).  The layout is VERIFIED, not assumed: a workgroup that meets a
+// point of another image, or a point without a cell (non-finite coordinates: the image's base offset would no
+// longer be b * ppi), raises `need` and the generic kernels, launched behind it, redo the whole job; with
+// `need` clear they return at once.  Workgroup b runs on XCD b % 8, where the gather reads image b.
+constexpr int kGroupCells = 8192;  // cells per image the LDS counters hold (a 512 x 1024 image)
+__global__ __launch_bounds__(1024) void p2i_bin_grouped_kernel(
+    const float *__restrict__ points, const float *__restrict__ feat,
+    const int *__restrict__ batch_inds, int *__restrict__ offs, float4 *__restrict__ srec,
+    unsigned *__restrict__ fmax_bits, unsigned *__restrict__ need, int ppi, int channels, int h, int w,
+    int cells_x, int cells_y) {
+  __shared__ int cnt[kGroupCells];
+  __shared__ int wsum[16];
+  __shared__ int carry, bad;
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int cpi = cells_x * cells_y;
+  const long base = (long)b * ppi;
+  for (int i = tid; i < cpi; i += 1024) cnt[i] = 0;
+  if (tid == 0) bad = 0;
+  __syncthreads();
+  bool wrong = false;
+  for (int i = tid; i < ppi; i += 1024) {
+    const long pid = base + i;
+    const int c = cell_of_point(points[pid * 2 + 0], points[pid * 2 + 1], h, w, cells_x, cells_y);
+    wrong |= batch_inds[pid] != b || c < 0;
+    if (c >= 0) atomicAdd(&cnt[c], 1);
+  }
+  if (wrong) bad = 1;
+  __syncthreads();
+  if (bad) {  // every thread of the workgroup sees the same value
+    if (tid == 0) atomicOr(need, 1u);
+    return;
+  }
+  // exclusive scan of the counters -> first record of every cell (the image starts at b * ppi)
+  if (tid == 0) carry = (int)base;
+  __syncthreads();
+  for (int c0 = 0; c0 < cpi; c0 += 1024) {
+    const int i = c0 + tid;
+    const int v = i < cpi ? cnt[i] : 0;
+    int incl = v;
+    for (int m = 1; m < 64; m <<= 1) {
+      const int u = __shfl_up(incl, m);
+      if ((tid & 63) >= m) incl += u;
+    }
+    if ((tid & 63) == 63) wsum[tid >> 6] = incl;
+    __syncthreads();
+    int pre = carry;
+    for (int wv = 0; wv < (tid >> 6); ++wv) pre += wsum[wv];
+    if (i < cpi) cnt[i] = pre + incl - v;
+    __syncthreads();
+    if (tid == 1023) carry = pre + incl;
+    __syncthreads();
+  }
+  float fm = 0.f;
+  for (int i = tid; i < ppi; i += 1024) {
+    const long pid = base + i;
+    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+    const int c = cell_of_point(py, px, h, w, cells_x, cells_y);
+    const int pos = atomicAdd(&cnt[c], 1);
+    srec[pos] = make_float4(py, px, channels == 1 ? feat[pid] : 0.f, __int_as_float((int)pid));
+    for (int ch = 0; ch < channels; ++ch) fm = __builtin_fmaxf(fm, __builtin_fabsf(feat[(size_t)pid * channels + ch]));
+  }
+  __syncthreads();
+  for (int i = tid; i < cpi; i += 1024) offs[(long)b * cpi + i] = cnt[i];  // END offsets, as the scatter leaves them
+  for (int m = 1; m < 64; m <<= 1) fm = __builtin_fmaxf(fm, __shfl_xor(fm, m));
+  if ((tid & 63) == 0 && __float_as_uint(fm) > *reinterpret_cast<volatile unsigned *>(fmax_bits))
     atomicMax(fmax_bits, __float_as_uint(fm));
 }
 
@@ -1016,19 +1091,28 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
   SN_REQUIRE(tiles / 4 + 1 < (1L << 31), "%s: too many tiles", fn);
   char *wp = static_cast<char *>(workspace);
   unsigned *fmax_bits = reinterpret_cast<unsigned *>(wp); wp += 256;   // max |feature| (bits), for the error band
-  SN_HIP(hipMemsetAsync(fmax_bits, 0, 4, s));
+  unsigned *need = fmax_bits + 1;   // != 0: the generic binning kernels have to run
   int *counts = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   int *offs = reinterpret_cast<int *>(wp); wp += sn::align_up((size_t)cells * 4, 256);
   float4 *srec = reinterpret_cast<float4 *>(wp);
+  const bool try_grouped = npoints > 0 && npoints % batch == 0 && cells_x * cells_y <= kGroupCells;
+  if (try_grouped) {
+    SN_HIP(hipMemsetAsync(fmax_bits, 0, 8, s));
+    p2i_bin_grouped_kernel<<<batch, 1024, 0, s>>>(points, feat, batch_inds, offs, srec, fmax_bits, need,
+                                                  npoints / batch, channels, h, w, cells_x, cells_y);
+  } else {
+    SN_HIP(hipMemsetAsync(fmax_bits, 0, 4, s));
+    SN_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(need), 1, 1, s));
+  }
   SN_HIP(hipMemsetAsync(counts, 0, (size_t)cells * 4, s));
   if (npoints > 0)
     p2i_bin_count_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, batch_inds, counts, npoints, batch,
-                                                             h, w, cells_x, cells_y);
-  p2i_bin_scan_kernel<<<batch, 1024, 0, s>>>(counts, offs, cells_x * cells_y);
+                                                             h, w, cells_x, cells_y, need);
+  p2i_bin_scan_kernel<<<batch, 1024, 0, s>>>(counts, offs, cells_x * cells_y, need);
   if (npoints > 0)
     p2i_bin_scatter_kernel<<<lin_blocks(npoints), 256, 0, s>>>(points, feat, batch_inds, offs, srec, fmax_bits,
                                                                npoints, channels, batch, h, w, cells_x,
-                                                               cells_y);
+                                                               cells_y, need);
   const int blocks = (int)((tiles + 3) / 4);
 #define SN_GATHER(NR)                                                                         \
   do {                                                                                        \

@@ -439,3 +439,43 @@ def test_hip_all_views_in_one_pass_equal_per_view_calls(projection, radii, dev):
     np.testing.assert_allclose(d1.grad.cpu().numpy(), d2.grad.cpu().numpy(), rtol=2e-5, atol=2e-6)
     sub = cdm.forward_views(base, [6, 2], radii)
     assert torch.equal(sub[0], all_maps[6]) and torch.equal(sub[1], all_maps[2])
+
+
+@pytest.mark.gpu
+def test_hip_binning_grouped_layout_and_its_fallbacks_agree(dev):
+    """The one-launch binning (image b owns points [b*n, (b+1)*n)) is verified on the device, not assumed: the
+    same cloud in grouped order, in shuffled order (same count per image, verification fails -> generic
+    kernels), with one non-finite point (no cell -> generic kernels) and with unequal counts per image (never
+    tried) must give the same maps, and ids that map back through the permutation."""
+    from sparenet_amd.cuda.p2i_op import ext
+
+    g = torch.Generator().manual_seed(77)
+    B, n, S, radii = 4, 2048, 64, [5.0, 7.0, 10.0]
+    pts = torch.rand(B * n, 2, generator=g) * (S + 6) - 3
+    feat = torch.rand(B * n, 1, generator=g)
+    bi = torch.arange(B, dtype=torch.int32).repeat_interleave(n)
+    bg = torch.zeros(B, 1, S, S)
+    out0, ids0 = ext.p2i_max_forward_multi_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, radii)
+    for r, R in enumerate(radii):
+        o, i = oracle.p2i_max_forward(pts.numpy(), feat.numpy(), bi.numpy(), bg.numpy(), R)
+        _close_maps(out0[r].cpu().numpy(), ids0[r].cpu().numpy(), o, i, f"grouped R={R}")
+    # shuffled: npoints % batch == 0 still holds, the layout check fails on the device
+    perm = torch.randperm(B * n, generator=g)
+    out1, ids1 = ext.p2i_max_forward_multi_gpu(pts[perm].to(dev), feat[perm].to(dev), bi[perm].to(dev), bg.to(dev), 0, radii)
+    assert torch.equal(out1, out0)
+    back = perm.to(dev)[ids1.clamp(min=0).long()]
+    assert torch.equal(torch.where(ids1 < 0, ids1.long(), back), ids0.long())
+    # one NaN point: it has no cell, so the grouped kernel hands over; the maps only lose that point
+    pts2 = pts.clone()
+    pts2[5] = float("nan")
+    out2, ids2 = ext.p2i_max_forward_multi_gpu(pts2.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, radii)
+    for r, R in enumerate(radii):
+        o, i = oracle.p2i_max_forward(pts2.numpy(), feat.numpy(), bi.numpy(), bg.numpy(), R)
+        _close_maps(out2[r].cpu().numpy(), ids2[r].cpu().numpy(), o, i, f"nan R={R}")
+    # unequal counts per image
+    keep = torch.ones(B * n, dtype=torch.bool)
+    keep[:7] = False
+    out3, ids3 = ext.p2i_max_forward_multi_gpu(pts[keep].to(dev), feat[keep].to(dev), bi[keep].to(dev), bg.to(dev), 0, radii)
+    for r, R in enumerate(radii):
+        o, i = oracle.p2i_max_forward(pts[keep].numpy(), feat[keep].numpy(), bi[keep].numpy(), bg.numpy(), R)
+        _close_maps(out3[r].cpu().numpy(), ids3[r].cpu().numpy(), o, i, f"ragged R={R}")
