@@ -171,6 +171,11 @@ int sn_p2i_max_forward(const float *points, const float *feat,
  * to what sn_p2i_max_forward returns for that radius. */
 size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels,
                                         int h, int w);
+/* Test hook, not part of the reference surface: the renderer's two fp32 series in
+ * u = r^2 / R^2 -- weight[i] ~ (cos(pi sqrt(u)) + 1) / 2 and slope[i] ~
+ * sin(pi sqrt(u)) / (pi sqrt(u)) -- evaluated on the device for n values of u in
+ * [0, 1]; the tests pin the error bounds the forward's decision band relies on. */
+int sn_p2i_series(const float *u, int n, float *weight, float *slope, void *stream);
 int sn_p2i_max_forward_multi(const float *points, const float *feat,
                              const int *batch_inds, const float *background,
                              int npoints, int channels, int batch, int h, int w,

@@ -479,3 +479,27 @@ def test_hip_binning_grouped_layout_and_its_fallbacks_agree(dev):
     for r, R in enumerate(radii):
         o, i = oracle.p2i_max_forward(pts[keep].numpy(), feat[keep].numpy(), bi[keep].numpy(), bg.numpy(), R)
         _close_maps(out3[r].cpu().numpy(), ids3[r].cpu().numpy(), o, i, f"ragged R={R}")
+
+
+@pytest.mark.gpu
+def test_hip_weight_series_error_bounds(dev):
+    """The forward decides winners with an fp32 series of the cosine weight and only evaluates winners exactly;
+    that is sound iff |series - exact| stays inside the band the kernel assumes (kWeightErr = 1.5e-6, of which
+    1.1e-6 is the series' own share: 4e-7 is reserved for the roundings of u and of sqrtf).  Every fp32 u of a
+    fine grid plus the neighbourhood of both ends; the backward's slope series likewise (5e-7)."""
+    import ctypes
+    from sparenet_amd import _lib as L
+
+    u = np.concatenate([np.linspace(0.0, 1.0, 2_000_001, dtype=np.float64).astype(np.float32),
+                        np.nextafter(np.float32(0), np.float32(1)) * np.arange(1, 1000, dtype=np.float32),
+                        np.float32(1) - np.arange(0, 1000, dtype=np.float32) * np.float32(2.0 ** -24)])
+    ut = torch.from_numpy(u).to(dev)
+    w, sl = torch.empty_like(ut), torch.empty_like(ut)
+    rc = L.lib().sn_p2i_series(L.fptr(ut, "u"), ctypes.c_int(ut.numel()), L.fptr(w, "w"), L.fptr(sl, "sl"),
+                               ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    t = np.sqrt(u.astype(np.float64))
+    w_ref = np.cos(np.pi * t) * 0.5 + 0.5
+    s_ref = np.where(t > 0, np.sin(np.pi * t) / (np.pi * np.maximum(t, 1e-300)), 1.0)
+    assert np.abs(w.cpu().numpy().astype(np.float64) - w_ref).max() <= 1.1e-6
+    assert np.abs(sl.cpu().numpy().astype(np.float64) - s_ref).max() <= 5e-7
