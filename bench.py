@@ -157,7 +157,7 @@ class HotPath:
                 acc = s if acc is None else acc + s
         else:
             maps = self.render.forward_views(p4, range(N_VIEWS), self.radius_list)       # [V,B,R,S,S]
-            acc = maps.mean(dim=(1, 2, 3, 4)).sum()
+            acc = maps.mean() * N_VIEWS   # = the sum over the views of the mean map (one full reduction)
         acc.backward()
         return acc
 

@@ -167,8 +167,11 @@ int sn_p2i_max_forward(const float *points, const float *feat,
 /* Several kernel radii over the same points / features / background in one pass
  * (ComputeDepthMaps calls p2i once per radius with identical inputs,
  * utils/p2i_utils.py:230-251): radii[nradii] is a HOST array, 1 <= nradii <= 4;
- * out / out_ids hold nradii consecutive [batch,channels,h,w] tensors, each equal
- * to what sn_p2i_max_forward returns for that radius. */
+ * out / out_ids hold nradii [batch,channels,h,w] tensors, each equal to what
+ * sn_p2i_max_forward returns for that radius: one after the other ([R,B,C,H,W],
+ * image_major = 0) or interleaved per image ([B,R,C,H,W], image_major = 1: the layout
+ * of the [B, len(radius_list), S, S] tensor ComputeDepthMaps returns, so that nothing
+ * has to be transposed afterwards; radii <= 16 px). */
 size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels,
                                         int h, int w);
 /* Test hook, not part of the reference surface: the renderer's two fp32 series in
@@ -179,8 +182,8 @@ int sn_p2i_series(const float *u, int n, float *weight, float *slope, void *stre
 int sn_p2i_max_forward_multi(const float *points, const float *feat,
                              const int *batch_inds, const float *background,
                              int npoints, int channels, int batch, int h, int w,
-                             const float *radii, int nradii, float *out,
-                             int *out_ids, void *workspace,
+                             const float *radii, int nradii, int image_major,
+                             float *out, int *out_ids, void *workspace,
                              size_t workspace_bytes, void *stream);
 /* points_grad[npoints,2], feat_grad[npoints,channels],
  * background_grad[batch,channels,h,w] are fully overwritten.
@@ -196,15 +199,17 @@ int sn_p2i_max_backward(const float *out_grad, const int *out_ids,
                         size_t workspace_bytes, void *stream);
 /* Backward of nradii splats that share points / features (the gradients of the radii
  * are summed, which is what autograd does with the reference's per-radius calls).
- * out_grad / out_ids: nradii consecutive [batch,channels,h,w] tensors.  Pixel-centric:
+ * out_grad / out_ids: nradii [batch,channels,h,w] tensors in the layout of the forward
+ * (image_major as there).  Pixel-centric:
  * every pixel adds its terms to its winner in 64-bit fixed point (integer atomics), so
  * the sums are exact and bit-reproducible. */
 size_t sn_p2i_max_backward_multi_workspace_bytes(int npoints, int channels);
 int sn_p2i_max_backward_multi(const float *out_grad, const int *out_ids,
                               const float *points, const float *feat,
                               int npoints, int channels, int batch, int h, int w,
-                              const float *radii, int nradii, float *points_grad,
-                              float *feat_grad, float *background_grad,
+                              const float *radii, int nradii, int image_major,
+                              float *points_grad, float *feat_grad,
+                              float *background_grad,
                               void *workspace, size_t workspace_bytes,
                               void *stream);
 /* replaces p2i_op.p2i_sum_forward_gpu / p2i_sum_backward_gpu

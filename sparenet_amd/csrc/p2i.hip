@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     const float *__restrict__ feat, const float *__restrict__ background,
     const float4 *__restrict__ srec, const int *__restrict__ offs, const unsigned *__restrict__ fmax_bits,
     int channels, int batch, int h, int w, int cells_x, int cells_y, RadiiArg ra,
-    float *__restrict__ out, int *__restrict__ out_ids) {
+    float *__restrict__ out, int *__restrict__ out_ids, long obstride, long orstride) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   long tile = (long)blockIdx.x * 4 + wave;  // (b, c, cy, cx), cx fastest
   const long tiles = (long)batch * channels * cells_y * cells_x;
@@ -613,7 +613,9 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     v = f * cos_weight(__builtin_sqrtf(s2), radius);
     low = 0xFFFFFFFEu - (unsigned)pid;
   };
-  const size_t image = (size_t)batch * channels * h * w;  // one output tensor per radius
+  // output position: image b, radius k, channel c -> b * obstride + k * orstride + c * h * w (+ pixel): radius-major
+  // [R,B,C,H,W] or image-major [B,R,C,H,W], chosen by the caller
+  const size_t oplane = (size_t)b * obstride + (size_t)c * h * w;
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     float best_v = bg;          // the reference replaces only on strictly greater: the background wins ties
@@ -659,7 +661,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
       }
     }
     if (valid) {
-      const size_t e = k * image + plane + (size_t)y * w + x;
+      const size_t e = (size_t)k * orstride + oplane + (size_t)y * w + x;
       out[e] = best_v;
       out_ids[e] = best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low);
     }
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     const float *__restrict__ points, const float *__restrict__ feat,
     const unsigned *__restrict__ absmax, float *__restrict__ background_grad,
     long long *__restrict__ acc_pts, long long *__restrict__ acc_feat, int channels, int batch,
-    int h, int w, RadiiArg ra, int nradii, float min_radius) {
+    int h, int w, RadiiArg ra, int nradii, float min_radius, long obstride, long orstride) {
   // One wave per 8x8 tile (lane = pixel).  Neighbouring pixels, and the radii of one pixel,
   // often share their winner: the terms first meet in a per-wave LDS hash table keyed by the
   // point id (LDS integer atomics), and every distinct winner of the tile then costs three
@@ -980,7 +982,7 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
   const double scale = fixed_scale(absmax, min_radius);
   const size_t plane = ((size_t)b * channels + c) * h * w;
   const size_t e = plane + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
-  const long image = (long)batch * channels * h * w;
+  const size_t oe = (size_t)b * obstride + (size_t)c * h * w + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
   for (int i = lane; i < kAccSlots; i += 64) {
     keys[wave][i] = -1;
     vals[wave][i][0] = vals[wave][i][1] = vals[wave][i][2] = 0ull;
@@ -988,8 +990,8 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   float bg = 0.f;
   for (int k = 0; k < nradii; ++k) {
-    const float gk = valid ? out_grad[k * image + e] : 0.f;
-    const int pid = valid ? out_ids[k * image + e] : -1;
+    const float gk = valid ? out_grad[(size_t)k * orstride + oe] : 0.f;
+    const int pid = valid ? out_ids[(size_t)k * orstride + oe] : -1;
     if (pid < 0) {
       bg += gk;
       continue;
@@ -1075,7 +1077,7 @@ float max_sq_inside_host(float radius) {
 // values + ids of nradii splats that share points / features / background (radii <= 16 px)
 int tile_forward(const char *fn, const float *points, const float *feat, const int *batch_inds,
                  const float *background, int npoints, int channels, int batch, int h, int w,
-                 const float *radii, int nradii, float *out, int *out_ids, void *workspace,
+                 const float *radii, int nradii, int image_major, float *out, int *out_ids, void *workspace,
                  hipStream_t s) {
   RadiiArg ra = {};
   float rmax = 0.f;
@@ -1117,14 +1119,16 @@ int tile_forward(const char *fn, const float *points, const float *feat, const i
                                                                npoints, channels, batch, h, w, cells_x,
                                                                cells_y, need);
   const int blocks = (int)((tiles + 3) / 4);
+  const long chw = (long)channels * h * w;
+  const long obstride = image_major ? (long)nradii * chw : chw, orstride = image_major ? chw : (long)batch * chw;
 #define SN_GATHER(NR)                                                                         \
   do {                                                                                        \
     if (channels == 1)                                                                        \
       p2i_gather_max_kernel<NR, true><<<blocks, 256, 0, s>>>(feat, background, srec, offs,      \
-          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);              \
+          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids, obstride, orstride); \
     else                                                                                      \
       p2i_gather_max_kernel<NR, false><<<blocks, 256, 0, s>>>(feat, background, srec, offs,     \
-          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids);              \
+          fmax_bits, channels, batch, h, w, cells_x, cells_y, ra, out, out_ids, obstride, orstride); \
   } while (0)
   if (sn::prof_enabled()) sn::prof_begin("p2i_max_splat", s);
   switch (nradii) {
@@ -1178,7 +1182,7 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
   hipStream_t s = sn::as_stream(stream);
   if (radius <= kTileMaxRadius && workspace_bytes >= tile_workspace_bytes(npoints, batch, h, w))
     return tile_forward("sn_p2i_max_forward", points, feat, batch_inds, background, npoints,
-                        channels, batch, h, w, &radius, 1, out, out_ids, workspace, s);
+                        channels, batch, h, w, &radius, 1, 0, out, out_ids, workspace, s);
   unsigned long long *img = static_cast<unsigned long long *>(workspace);
   const long px = (long)batch * channels * h * w;
   p2i_max_init_kernel<<<lin_blocks(px), 256, 0, s>>>(background, img, px);
@@ -1208,8 +1212,9 @@ extern "C" int sn_p2i_max_forward(const float *points, const float *feat, const 
 extern "C" int sn_p2i_max_forward_multi(const float *points, const float *feat,
                                         const int *batch_inds, const float *background,
                                         int npoints, int channels, int batch, int h, int w,
-                                        const float *radii, int nradii, float *out, int *out_ids,
-                                        void *workspace, size_t workspace_bytes, void *stream) {
+                                        const float *radii, int nradii, int image_major, float *out,
+                                        int *out_ids, void *workspace, size_t workspace_bytes,
+                                        void *stream) {
   SN_REQUIRE(background && out && out_ids && workspace && radii,
              "sn_p2i_max_forward_multi: null pointer");
   SN_REQUIRE(npoints == 0 || (points && feat && batch_inds), "sn_p2i_max_forward_multi: null pointer");
@@ -1226,7 +1231,9 @@ extern "C" int sn_p2i_max_forward_multi(const float *points, const float *feat,
   hipStream_t s = sn::as_stream(stream);
   if (rmax <= kTileMaxRadius)
     return tile_forward("sn_p2i_max_forward_multi", points, feat, batch_inds, background, npoints,
-                        channels, batch, h, w, radii, nradii, out, out_ids, workspace, s);
+                        channels, batch, h, w, radii, nradii, image_major, out, out_ids, workspace, s);
+  SN_REQUIRE(!image_major || nradii == 1,
+             "sn_p2i_max_forward_multi: the image-major layout needs radii <= %g px", (double)kTileMaxRadius);
   const size_t image = (size_t)batch * channels * h * w;
   for (int k = 0; k < nradii; ++k)  // large kernels: one global splat per radius
     if (int rc = sn_p2i_max_forward(points, feat, batch_inds, background, npoints, channels, batch,
@@ -1284,8 +1291,8 @@ extern "C" size_t sn_p2i_max_backward_multi_workspace_bytes(int npoints, int cha
 extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_ids,
                                          const float *points, const float *feat, int npoints,
                                          int channels, int batch, int h, int w, const float *radii,
-                                         int nradii, float *points_grad, float *feat_grad,
-                                         float *background_grad, void *workspace,
+                                         int nradii, int image_major, float *points_grad,
+                                         float *feat_grad, float *background_grad, void *workspace,
                                          size_t workspace_bytes, void *stream) {
   SN_REQUIRE(out_grad && out_ids && background_grad && workspace && radii,
              "sn_p2i_max_backward_multi: null pointer");
@@ -1317,7 +1324,9 @@ extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_i
   SN_REQUIRE(blocks < (1L << 31), "sn_p2i_max_backward_multi: image too large");
   p2i_max_bwd_accum_kernel<<<(int)blocks, 256, 0, s>>>(out_grad, out_ids, points, feat, absmax,
                                                        background_grad, acc_pts, acc_feat, channels,
-                                                       batch, h, w, ra, nradii, rmin);
+                                                       batch, h, w, ra, nradii, rmin,
+                                                       image_major ? (long)nradii * channels * h * w : (long)channels * h * w,
+                                                       image_major ? (long)channels * h * w : px);
   if (npoints > 0)
     p2i_max_bwd_finish_kernel<<<lin_blocks((long)npoints * (2 + channels)), 256, 0, s>>>(
         acc_pts, acc_feat, absmax, points_grad, feat_grad, (long)npoints * 2,

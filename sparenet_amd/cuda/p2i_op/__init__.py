@@ -64,14 +64,17 @@ class _Ext:
 
     @staticmethod
     def p2i_max_forward_multi_gpu(points, point_features, batch_inds, background, kernel_kind,
-                                  radii):
+                                  radii, image_major=False):
         """All radii of one ComputeDepthMaps call in one pass (sn_p2i_max_forward_multi):
-        returns out / ids of shape [len(radii), batch, channels, h, w]."""
+        returns out / ids of shape [len(radii), batch, channels, h, w], or, image_major,
+        [batch, len(radii), channels, h, w] (radii <= 16 px) -- the memory layout of the
+        [B, len(radius_list), S, S] tensor ComputeDepthMaps returns."""
         if kernel_kind != 0:
             raise ValueError("p2i: only kernel_kind 0 ('cos') exists")
         n, c, b, h, w = _shapes(points, point_features, background)
         nr = len(radii)
-        out = torch.empty((nr,) + tuple(background.shape), dtype=background.dtype,
+        shape = (b, nr) + tuple(background.shape[1:]) if image_major else (nr,) + tuple(background.shape)
+        out = torch.empty(shape, dtype=background.dtype,
                           device=background.device)
         ids = torch.empty(out.shape, dtype=torch.int32, device=background.device)
         host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
@@ -81,7 +84,7 @@ class _Ext:
             code = _lib.lib().sn_p2i_max_forward_multi(
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
                 _lib.iptr(batch_inds, "batch_inds"), _lib.fptr(background, "background"),
-                n, c, b, h, w, host_radii, nr, _lib.fptr(out, "out"),
+                n, c, b, h, w, host_radii, nr, int(bool(image_major)), _lib.fptr(out, "out"),
                 _lib.iptr(ids, "out_point_ids"), ctypes.c_void_p(ws.data_ptr()),
                 ctypes.c_size_t(nbytes), _lib.stream_of(background))
         _lib.check(code, "sn_p2i_max_forward_multi")
@@ -121,15 +124,19 @@ class _Ext:
 
     @staticmethod
     def p2i_max_backward_multi_gpu(out_grad, out_point_ids, points, point_features, kernel_kind,
-                                   radii):
-        """out_grad / out_point_ids [len(radii), B, C, H, W] -> gradients summed over the radii
-        (sn_p2i_max_backward_multi: exact fixed-point accumulation, bit-reproducible)."""
+                                   radii, image_major=False):
+        """out_grad / out_point_ids [len(radii), B, C, H, W] (image_major: [B, len(radii), C, H, W])
+        -> gradients summed over the radii (sn_p2i_max_backward_multi: exact fixed-point
+        accumulation, bit-reproducible)."""
         n = points.size(0)
         c = point_features.size(1)
-        nr, b, _, h, w = out_grad.shape
+        if image_major:
+            b, nr, _, h, w = out_grad.shape
+        else:
+            nr, b, _, h, w = out_grad.shape
         points_grad = torch.empty_like(points)
         feat_grad = torch.empty_like(point_features)
-        bg_grad = torch.empty(out_grad.shape[1:], dtype=out_grad.dtype, device=out_grad.device)
+        bg_grad = torch.empty((b, c, h, w), dtype=out_grad.dtype, device=out_grad.device)
         host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
         with torch.cuda.device_of(out_grad):
             nbytes = _lib.lib().sn_p2i_max_backward_multi_workspace_bytes(n, c)
@@ -137,7 +144,7 @@ class _Ext:
             code = _lib.lib().sn_p2i_max_backward_multi(
                 _lib.fptr(out_grad, "out_grad"), _lib.iptr(out_point_ids, "out_point_ids"),
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
-                n, c, b, h, w, host_radii, nr, _lib.fptr(points_grad, "points_grad"),
+                n, c, b, h, w, host_radii, nr, int(bool(image_major)), _lib.fptr(points_grad, "points_grad"),
                 _lib.fptr(feat_grad, "point_features_grad"), _lib.fptr(bg_grad, "background_grad"),
                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(out_grad))
         _lib.check(code, "sn_p2i_max_backward_multi")
@@ -247,24 +254,29 @@ class P2IMaxFunction(Function):
 
 class P2IMaxMultiFunction(Function):
     """P2IMaxFunction for several kernel radii at once: returns [len(radii), B, C, H, W], slice
-    r equal to P2IMaxFunction.apply(..., radii[r]).  The forward shares one binning and one
-    pixel walk between the radii; the backward adds the radii's gradients in one pass."""
+    r equal to P2IMaxFunction.apply(..., radii[r]) -- or, image_major, [B, len(radii), C, H, W]
+    (written in that layout by the kernel: no transpose, and the gradient arrives contiguous).
+    The forward shares one binning and one pixel walk between the radii; the backward adds the
+    radii's gradients in one pass."""
 
     @staticmethod
-    def forward(ctx, points, point_features, batch_inds, background, kernel_kind, radii):
+    def forward(ctx, points, point_features, batch_inds, background, kernel_kind, radii, image_major=False):
+        native = bool(image_major) and max(float(r) for r in radii) <= 16.0   # the kernel writes [B,R,...] itself
         out, winner_ids = ext.p2i_max_forward_multi_gpu(
-            *_c(points, point_features, batch_inds, background), kernel_kind, radii)
+            *_c(points, point_features, batch_inds, background), kernel_kind, radii, native)
         ctx.save_for_backward(points, point_features, winner_ids, batch_inds.contiguous())
-        ctx.kind_radii = (kernel_kind, tuple(float(r) for r in radii))
-        return out
+        ctx.kind_radii = (kernel_kind, tuple(float(r) for r in radii), native, bool(image_major) and not native)
+        return out.transpose(0, 1).contiguous() if (image_major and not native) else out
 
     @staticmethod
     def backward(ctx, out_grad):
         points, point_features, winner_ids, batch_inds = ctx.saved_tensors
-        kind, radii = ctx.kind_radii
+        kind, radii, native, transposed = ctx.kind_radii
+        if transposed:
+            out_grad = out_grad.transpose(0, 1)
         g_points, g_feat, g_bg = ext.p2i_max_backward_multi_gpu(
-            out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radii)
-        return g_points, g_feat, None, g_bg, None, None
+            out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radii, native)
+        return g_points, g_feat, None, g_bg, None, None, None
 
 
 _kernel_kind_dict = {"cos": 0}

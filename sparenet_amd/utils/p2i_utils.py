@@ -270,9 +270,8 @@ class ComputeDepthMaps(torch.nn.Module):
                                                  0, chunk[0]))
             else:
                 stacked = P2IMaxMultiFunction.apply(pixel_ijs, point_features, batch_inds,
-                                                    background, 0, chunk)   # [r,B,1,S,S]
-                maps.append(stacked.transpose(0, 1).reshape(batch, len(chunk), self.image_size,
-                                                            self.image_size))
+                                                    background, 0, chunk, True)   # [B,r,1,S,S], written that way
+                maps.append(stacked.view(batch, len(chunk), self.image_size, self.image_size))
         return maps[0] if len(maps) == 1 else torch.cat(maps, dim=1)
 
     def forward_views(self, data, view_ids=None, radius_list=[10.0]):
@@ -295,5 +294,5 @@ class ComputeDepthMaps(torch.nn.Module):
         if len(radii) == 1:
             maps = P2IMaxFunction.apply(pixel_ijs, point_features, batch_inds, background, 0, radii[0])
             return maps.view(nv, batch, 1, s, s)
-        stacked = P2IMaxMultiFunction.apply(pixel_ijs, point_features, batch_inds, background, 0, radii)
-        return stacked.view(len(radii), nv, batch, s, s).permute(1, 2, 0, 3, 4)      # [V,B,R,S,S]
+        stacked = P2IMaxMultiFunction.apply(pixel_ijs, point_features, batch_inds, background, 0, radii, True)
+        return stacked.view(nv, batch, len(radii), s, s)      # [V*B,R,1,S,S] as the kernel wrote it

@@ -157,6 +157,15 @@ def test_hip_multi_radius_matches_oracle_and_single(B, n, C, H, W, radii, dev):
     bg = torch.rand(B, C, H, W, generator=g) * 0.1
     out, ids = ext.p2i_max_forward_multi_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, radii)
     assert out.shape == (len(radii), B, C, H, W)
+    if max(radii) <= 16.0:   # the image-major layout holds the same maps, [B, R, ...] instead of [R, B, ...]
+        out_im, ids_im = ext.p2i_max_forward_multi_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, radii,
+                                                       image_major=True)
+        assert torch.equal(out_im.transpose(0, 1), out) and torch.equal(ids_im.transpose(0, 1), ids)
+        og = torch.rand(out.shape, generator=torch.Generator().manual_seed(3)).to(dev)
+        g_a = ext.p2i_max_backward_multi_gpu(og, ids, pts.to(dev), feat.to(dev), 0, radii)
+        g_b = ext.p2i_max_backward_multi_gpu(og.transpose(0, 1).contiguous(), ids_im, pts.to(dev), feat.to(dev), 0,
+                                             radii, image_major=True)
+        assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
     for r, R in enumerate(radii):
         o1, i1 = ext.p2i_max_forward_gpu(pts.to(dev), feat.to(dev), bi.to(dev), bg.to(dev), 0, R)
         assert torch.equal(out[r], o1) and torch.equal(ids[r], i1), R

@@ -17,7 +17,7 @@ def step():
             m = cdm(p, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
             acc = m if acc is None else acc + m
     else:
-        acc = cdm.forward_views(p, range(8), [5.0, 7.0, 10.0]).mean(dim=(1, 2, 3, 4)).sum()
+        acc = cdm.forward_views(p, range(8), [5.0, 7.0, 10.0]).mean() * 8
     acc.backward()
 for _ in range(2): step()
 torch.cuda.synchronize()
