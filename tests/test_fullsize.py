@@ -272,3 +272,39 @@ def test_randomised_sweep_at_large_sizes(dev):
         assert np.array_equal(c1.cpu().numpy(), o1) and np.array_equal(c2.cpu().numpy(), o2), tag
         cases += 1
     assert cases >= 3
+
+
+@pytest.mark.gpu
+def test_emd_mixed_xcd_teams_fall_back_to_coherent_stores():
+    """A team whose workgroups all sit on one XCD keeps its stores in that XCD's L2 (plain stores); a team with
+    a workgroup on another XCD must not.  SN_EMD_DIAG=4 makes every workgroup take a slot of the NEIGHBOUR
+    XCD's team, so every team is mixed: the run (a fresh process -- the switch is read once) must report zero
+    single-XCD teams and still match the oracle bit for bit; without the switch all 32 teams qualify."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import oracle
+import sparenet_amd._lib as L
+from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
+g = torch.Generator().manual_seed(4242)
+b, n = 32, 2048
+x, y = torch.rand(b, n, 3, generator=g), torch.rand(b, n, 3, generator=g)
+d0, a0 = oracle.emd_forward(x.numpy(), y.numpy(), 0.005, 12, mt=True)
+dev = torch.device("cuda:0")
+d, a, ws = emd_forward_raw(x.to(dev), y.to(dev), 0.005, 12, return_workspace=True)
+torch.cuda.synchronize()
+import ctypes
+L.lib().sn_emd_diag_offset.restype = ctypes.c_size_t
+off = L.lib().sn_emd_diag_offset(b, n)
+local_teams = int(ws[off:off + 8 * 16].view(torch.int64)[12])
+print("RESULT", int(np.array_equal(a.cpu().numpy(), a0)), int(np.array_equal(d.cpu().numpy(), d0)), local_teams)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for diag, want_local in (("4", 0), ("1", 32)):
+        env = dict(os.environ, SN_EMD_DIAG=diag)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+        assert line, out.stderr[-2000:]
+        same_a, same_d, local_teams = (int(v) for v in line[0].split()[1:])
+        assert same_a == 1 and same_d == 1, (diag, line)
+        assert local_teams == want_local, (diag, local_teams)

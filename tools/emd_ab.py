@@ -22,6 +22,14 @@ if "--parity" in sys.argv:
         d, a = emd_forward_raw(X[:b].to(dev), Y[:b].to(dev), 0.005, iters, st)
         print(mode, "parity b", b, "iters", iters, bool(np.array_equal(a.cpu().numpy(), a0)),
               bool(np.array_equal(d.cpu().numpy(), d0)), int(st[0]) == aux["pairs_eff"], flush=True)
+if "--parity32" in sys.argv:   # the benched batch (XCD-local teams), 50 iterations
+    x, y = X.numpy(), Y.numpy()
+    d0, a0, aux = oracle.emd_forward(x, y, 0.005, 50, mt=True, return_aux=True)
+    for rep in range(3):
+        st = torch.zeros(2, dtype=torch.int64, device=dev)
+        d, a = emd_forward_raw(X.to(dev), Y.to(dev), 0.005, 50, st)
+        print(mode, "parity b 32 iters 50 run", rep, bool(np.array_equal(a.cpu().numpy(), a0)),
+              bool(np.array_equal(d.cpu().numpy(), d0)), int(st[0]) == aux["pairs_eff"], flush=True)
 for b in ((32,) if os.environ.get("AB_QUICK") else (32, 4, 1)):
     x, y = X[:b].to(dev), Y[:b].to(dev)
     for iters in ((50,) if os.environ.get("AB_QUICK") else (1, 10, 50)):
@@ -41,6 +49,7 @@ if os.environ.get("SN_EMD_DIAG"):
         off = _L.lib().sn_emd_diag_offset(b, N)
         v = ws[off:off + 8 * (16 + 64 * 64)].view(torch.int64).cpu().numpy()
         names = ["compact", "-", "bid", "bar1", "getmax", "bar2", "assign", "bar3"]
+        print("teams with every workgroup on one XCD (plain stores):", int(v[12]))
         print("team 0 / wg 0 phase time, us over the call:", {n_: round(float(v[4 + i]) / 100.0, 1) for i, n_ in enumerate(names)})
         if os.environ.get("SN_EMD_DIAG") == "2":
             t = v[16:16 + 50 * 64].reshape(50, 8, 8) / 100.0   # [it, wg, phase] us
