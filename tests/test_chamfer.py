@@ -220,11 +220,12 @@ def test_hip_full_size_properties(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,n,m,kind", [(2, 3000, 1700, "uniform"), (1, 5000, 5000, "far"), (3, 513, 2049, "lattice"),
-                                        (1, 20000, 7, "uniform")])
+                                        (1, 20000, 7, "uniform"), (1, 30000, 9000, "uniform")])
 def test_hip_backward_bit_exact_incl_long_inverse_lists(b, n, m, kind, dev):
     """Backward against the oracle (= the reference CPU order), bit for bit.  "far": every query of one cloud
     shares ONE neighbour in the other (an inverse list of thousands of entries: the heap-sort path); the
-    7-point cloud gives lists of ~3000 entries each."""
+    7-point cloud gives lists of ~3000 entries each; 30000 + 9000 points exceed the LDS counters of the
+    one-launch list builder (the three generic kernels run)."""
     rng = np.random.default_rng(n + m)
     x = rng.random((b, n, 3), dtype=np.float32)
     y = rng.random((b, m, 3), dtype=np.float32)
