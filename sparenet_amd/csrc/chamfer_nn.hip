@@ -357,11 +357,8 @@ extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, i
   int *cell_of = reinterpret_cast<int *>(p);  // sort scratch, shared by the two clouds
   if (sn::prof_enabled()) sn::prof_begin("chamfer_fwd", s);
   for (NnSide *side : {&s1, &s2}) {
-    const long total = (long)b * side->n;
-    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    SN_REQUIRE(cloud_sort_count(b, side->n, side->xyz, side->bbox, side->hist, cell_of, s) == 0,
+    SN_REQUIRE(cloud_sort(b, side->n, side->xyz, side->bbox, side->hist, cell_of, side->perm, s) == 0,
                "sn_chamfer_forward_sorted: cannot size the sort kernel's LDS");
-    cloud_sort_scatter_kernel<<<blocks, 256, 0, s>>>(side->n, cell_of, side->hist, side->perm, total);
     const long sbs = (long)b * side->nsb;
     nn_prepare_kernel<<<(int)((sbs + 3) / 4 < 4096 ? (sbs + 3) / 4 : 4096), 256, 0, s>>>(b, *side);
   }

@@ -1327,12 +1327,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
-  SN_REQUIRE(cloud_sort_count(b, n, xyz2, ws.bbox, ws.hist, ws.cell_of, s) == 0,
+  SN_REQUIRE(cloud_sort(b, n, xyz2, ws.bbox, ws.hist, ws.cell_of, ws.tperm, s) == 0,
              "sn_emd_forward: cannot size the sort kernel's LDS");
-  cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist, ws.tperm, total);
-  SN_REQUIRE(cloud_sort_count(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, s) == 0,
+  SN_REQUIRE(cloud_sort(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, ws.perm1, s) == 0,
              "sn_emd_forward: cannot size the sort kernel's LDS");
-  cloud_sort_scatter_kernel<<<eblocks, 256, 0, s>>>(n, ws.cell_of, ws.hist1, ws.perm1, total);
   static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);

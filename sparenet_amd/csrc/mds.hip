@@ -601,9 +601,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     int *cell_of = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
     int *hist = reinterpret_cast<int *>(w); w += (size_t)b * kSortCells * 4;
     float *bbox = reinterpret_cast<float *>(w);
-    SN_REQUIRE(cloud_sort_count(b, n, xyz, bbox, hist, cell_of, s) == 0, "sn_mds: cannot size the sort kernel's LDS");
-    const long total = (long)b * n;
-    cloud_sort_scatter_kernel<<<lin_blocks(total), 256, 0, s>>>(n, cell_of, hist, perm, total);
+    SN_REQUIRE(cloud_sort(b, n, xyz, bbox, hist, cell_of, perm, s) == 0, "sn_mds: cannot size the sort kernel's LDS");
     const size_t lds = (size_t)ppt * 1024 * 8;
 #define SN_MDSC(P)                                                                               \
   {                                                                                              \
