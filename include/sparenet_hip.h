@@ -171,7 +171,8 @@ int sn_p2i_max_forward(const float *points, const float *feat,
  * sn_p2i_max_forward returns for that radius: one after the other ([R,B,C,H,W],
  * image_major = 0) or interleaved per image ([B,R,C,H,W], image_major = 1: the layout
  * of the [B, len(radius_list), S, S] tensor ComputeDepthMaps returns, so that nothing
- * has to be transposed afterwards; radii <= 16 px). */
+ * has to be transposed afterwards; radii <= 16 px).  background may be NULL = all zeros
+ * (what ComputeDepthMaps passes; radii <= 16 px): no tensor is allocated, filled or read. */
 size_t sn_p2i_max_multi_workspace_bytes(int npoints, int batch, int channels,
                                         int h, int w);
 /* Test hook, not part of the reference surface: the renderer's two fp32 series in
@@ -200,7 +201,7 @@ int sn_p2i_max_backward(const float *out_grad, const int *out_ids,
 /* Backward of nradii splats that share points / features (the gradients of the radii
  * are summed, which is what autograd does with the reference's per-radius calls).
  * out_grad / out_ids: nradii [batch,channels,h,w] tensors in the layout of the forward
- * (image_major as there).  Pixel-centric:
+ * (image_major as there); background_grad may be NULL (not wanted).  Pixel-centric:
  * every pixel adds its terms to its winner in 64-bit fixed point (integer atomics), so
  * the sums are exact and bit-reproducible. */
 size_t sn_p2i_max_backward_multi_workspace_bytes(int npoints, int channels);

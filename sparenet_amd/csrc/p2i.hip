@@ -488,7 +488,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   const float fx = (float)x, fy = (float)y;
   const float eps = __uint_as_float(*fmax_bits) * kWeightErr, band = 2.f * eps;
   constexpr unsigned kBg = 0xFFFFFFFFu;  // "position" of the background
-  const float bg = valid ? background[plane + (size_t)y * w + x] : 0.f;
+  const float bg = valid && background ? background[plane + (size_t)y * w + x] : 0.f;  // nullptr: all zeros
   float b1[NR], b2[NR], b3[NR];   // the three largest fast values seen (b1: also the pruning bound)
   unsigned j1[NR], j2[NR];        // sorted positions (srec index) of the first two
 #pragma unroll
@@ -1022,7 +1022,7 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 0), vals[wave][i][1]);
     atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 1), vals[wave][i][2]);
   }
-  if (valid) background_grad[e] = bg;
+  if (valid && background_grad) background_grad[e] = bg;
 }
 
 __global__ __launch_bounds__(256) void p2i_max_bwd_finish_kernel(
@@ -1215,8 +1215,7 @@ extern "C" int sn_p2i_max_forward_multi(const float *points, const float *feat,
                                         const float *radii, int nradii, int image_major, float *out,
                                         int *out_ids, void *workspace, size_t workspace_bytes,
                                         void *stream) {
-  SN_REQUIRE(background && out && out_ids && workspace && radii,
-             "sn_p2i_max_forward_multi: null pointer");
+  SN_REQUIRE(out && out_ids && workspace && radii, "sn_p2i_max_forward_multi: null pointer");
   SN_REQUIRE(npoints == 0 || (points && feat && batch_inds), "sn_p2i_max_forward_multi: null pointer");
   SN_REQUIRE(nradii >= 1 && nradii <= kMaxRadii, "sn_p2i_max_forward_multi: 1..%d radii (got %d)",
              kMaxRadii, nradii);
@@ -1234,6 +1233,8 @@ extern "C" int sn_p2i_max_forward_multi(const float *points, const float *feat,
                         channels, batch, h, w, radii, nradii, image_major, out, out_ids, workspace, s);
   SN_REQUIRE(!image_major || nradii == 1,
              "sn_p2i_max_forward_multi: the image-major layout needs radii <= %g px", (double)kTileMaxRadius);
+  SN_REQUIRE(background, "sn_p2i_max_forward_multi: a null (all-zero) background needs radii <= %g px",
+             (double)kTileMaxRadius);
   const size_t image = (size_t)batch * channels * h * w;
   for (int k = 0; k < nradii; ++k)  // large kernels: one global splat per radius
     if (int rc = sn_p2i_max_forward(points, feat, batch_inds, background, npoints, channels, batch,
@@ -1294,8 +1295,7 @@ extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_i
                                          int nradii, int image_major, float *points_grad,
                                          float *feat_grad, float *background_grad, void *workspace,
                                          size_t workspace_bytes, void *stream) {
-  SN_REQUIRE(out_grad && out_ids && background_grad && workspace && radii,
-             "sn_p2i_max_backward_multi: null pointer");
+  SN_REQUIRE(out_grad && out_ids && workspace && radii, "sn_p2i_max_backward_multi: null pointer");
   SN_REQUIRE(npoints == 0 || (points && feat && points_grad && feat_grad),
              "sn_p2i_max_backward_multi: null pointer");
   SN_REQUIRE(nradii >= 1 && nradii <= kMaxRadii, "sn_p2i_max_backward_multi: 1..%d radii (got %d)",

@@ -18,7 +18,7 @@ __all__ = ["p2i"]
 def _shapes(points, point_features, background):
     npoints = points.size(0)
     channels = point_features.size(1)
-    batch, bc, out_h, out_w = background.shape
+    batch, bc, out_h, out_w = background if isinstance(background, (tuple, list)) else background.shape
     if points.dim() != 2 or points.size(1) != 2:
         raise ValueError("p2i: points must be [npoints, 2]")
     if point_features.size(0) != npoints or bc != channels:
@@ -73,20 +73,23 @@ class _Ext:
             raise ValueError("p2i: only kernel_kind 0 ('cos') exists")
         n, c, b, h, w = _shapes(points, point_features, background)
         nr = len(radii)
-        shape = (b, nr) + tuple(background.shape[1:]) if image_major else (nr,) + tuple(background.shape)
-        out = torch.empty(shape, dtype=background.dtype,
-                          device=background.device)
-        ids = torch.empty(out.shape, dtype=torch.int32, device=background.device)
+        zero_bg = isinstance(background, (tuple, list))   # a SHAPE instead of a tensor: an all-zero background
+        shape = (b, nr, c, h, w) if image_major else (nr, b, c, h, w)
+        out = torch.empty(shape, dtype=points.dtype, device=points.device)
+        ids = torch.empty(out.shape, dtype=torch.int32, device=points.device)
         host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
-        with torch.cuda.device_of(background):
+        if zero_bg and max(float(r) for r in radii) > 16.0:
+            background, zero_bg = torch.zeros(b, c, h, w, dtype=points.dtype, device=points.device), False
+        with torch.cuda.device_of(points):
             nbytes = _lib.lib().sn_p2i_max_multi_workspace_bytes(n, b, c, h, w)
-            ws = torch.empty(nbytes, dtype=torch.uint8, device=background.device)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
             code = _lib.lib().sn_p2i_max_forward_multi(
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
-                _lib.iptr(batch_inds, "batch_inds"), _lib.fptr(background, "background"),
+                _lib.iptr(batch_inds, "batch_inds"),
+                ctypes.c_void_p(0) if zero_bg else _lib.fptr(background, "background"),
                 n, c, b, h, w, host_radii, nr, int(bool(image_major)), _lib.fptr(out, "out"),
                 _lib.iptr(ids, "out_point_ids"), ctypes.c_void_p(ws.data_ptr()),
-                ctypes.c_size_t(nbytes), _lib.stream_of(background))
+                ctypes.c_size_t(nbytes), _lib.stream_of(points))
         _lib.check(code, "sn_p2i_max_forward_multi")
         return out, ids
 
@@ -124,7 +127,7 @@ class _Ext:
 
     @staticmethod
     def p2i_max_backward_multi_gpu(out_grad, out_point_ids, points, point_features, kernel_kind,
-                                   radii, image_major=False):
+                                   radii, image_major=False, want_background_grad=True):
         """out_grad / out_point_ids [len(radii), B, C, H, W] (image_major: [B, len(radii), C, H, W])
         -> gradients summed over the radii (sn_p2i_max_backward_multi: exact fixed-point
         accumulation, bit-reproducible)."""
@@ -136,7 +139,8 @@ class _Ext:
             nr, b, _, h, w = out_grad.shape
         points_grad = torch.empty_like(points)
         feat_grad = torch.empty_like(point_features)
-        bg_grad = torch.empty((b, c, h, w), dtype=out_grad.dtype, device=out_grad.device)
+        bg_grad = (torch.empty((b, c, h, w), dtype=out_grad.dtype, device=out_grad.device)
+                   if want_background_grad else None)
         host_radii = (ctypes.c_float * nr)(*[float(r) for r in radii])
         with torch.cuda.device_of(out_grad):
             nbytes = _lib.lib().sn_p2i_max_backward_multi_workspace_bytes(n, c)
@@ -145,7 +149,8 @@ class _Ext:
                 _lib.fptr(out_grad, "out_grad"), _lib.iptr(out_point_ids, "out_point_ids"),
                 _lib.fptr(points, "points"), _lib.fptr(point_features, "point_features"),
                 n, c, b, h, w, host_radii, nr, int(bool(image_major)), _lib.fptr(points_grad, "points_grad"),
-                _lib.fptr(feat_grad, "point_features_grad"), _lib.fptr(bg_grad, "background_grad"),
+                _lib.fptr(feat_grad, "point_features_grad"),
+                _lib.fptr(bg_grad, "background_grad") if want_background_grad else ctypes.c_void_p(0),
                 ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(nbytes), _lib.stream_of(out_grad))
         _lib.check(code, "sn_p2i_max_backward_multi")
         return points_grad, feat_grad, bg_grad
@@ -256,14 +261,17 @@ class P2IMaxMultiFunction(Function):
     """P2IMaxFunction for several kernel radii at once: returns [len(radii), B, C, H, W], slice
     r equal to P2IMaxFunction.apply(..., radii[r]) -- or, image_major, [B, len(radii), C, H, W]
     (written in that layout by the kernel: no transpose, and the gradient arrives contiguous).
+    `background` may be a shape (B, C, H, W) instead of a tensor: an all-zero background that is never
+    allocated, filled or read (ComputeDepthMaps' case).
     The forward shares one binning and one pixel walk between the radii; the backward adds the
     radii's gradients in one pass."""
 
     @staticmethod
     def forward(ctx, points, point_features, batch_inds, background, kernel_kind, radii, image_major=False):
         native = bool(image_major) and max(float(r) for r in radii) <= 16.0   # the kernel writes [B,R,...] itself
+        bg = background if isinstance(background, (tuple, list)) else background.contiguous()
         out, winner_ids = ext.p2i_max_forward_multi_gpu(
-            *_c(points, point_features, batch_inds, background), kernel_kind, radii, native)
+            *_c(points, point_features, batch_inds), bg, kernel_kind, radii, native)
         ctx.save_for_backward(points, point_features, winner_ids, batch_inds.contiguous())
         ctx.kind_radii = (kernel_kind, tuple(float(r) for r in radii), native, bool(image_major) and not native)
         return out.transpose(0, 1).contiguous() if (image_major and not native) else out
@@ -275,7 +283,8 @@ class P2IMaxMultiFunction(Function):
         if transposed:
             out_grad = out_grad.transpose(0, 1)
         g_points, g_feat, g_bg = ext.p2i_max_backward_multi_gpu(
-            out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radii, native)
+            out_grad.contiguous(), winner_ids, *_c(points, point_features), kind, radii, native,
+            want_background_grad=ctx.needs_input_grad[3])
         return g_points, g_feat, None, g_bg, None, None, None
 
 

@@ -289,8 +289,12 @@ class ComputeDepthMaps(torch.nn.Module):
         s = self.image_size
         pixel_ijs, point_features = DepthProjectViewsFunction.apply(
             data, [self._host_mats[v] for v in view_ids], s)
-        background = torch.zeros(nv * batch, 1, s, s, dtype=data.dtype, device=data.device)
         batch_inds = self._batch_inds(nv * batch, npoints, data.device)
+        if len(radii) > 1 and max(radii) <= 16.0:   # the zero background as a shape: nothing to allocate or read
+            stacked = P2IMaxMultiFunction.apply(pixel_ijs, point_features, batch_inds, (nv * batch, 1, s, s), 0,
+                                                radii, True)
+            return stacked.view(nv, batch, len(radii), s, s)      # [V*B,R,1,S,S] as the kernel wrote it
+        background = torch.zeros(nv * batch, 1, s, s, dtype=data.dtype, device=data.device)
         if len(radii) == 1:
             maps = P2IMaxFunction.apply(pixel_ijs, point_features, batch_inds, background, 0, radii[0])
             return maps.view(nv, batch, 1, s, s)
