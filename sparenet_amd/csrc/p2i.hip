@@ -490,10 +490,12 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   constexpr unsigned kBg = 0xFFFFFFFFu;  // "position" of the background
   const float bg = valid && background ? background[plane + (size_t)y * w + x] : 0.f;  // nullptr: all zeros
   float b1[NR], b2[NR], b3[NR];   // the three largest fast values seen (b1: also the pruning bound)
+  float low1[NR];                 // b1 - band, kept next to b1
   unsigned j1[NR], j2[NR];        // sorted positions (srec index) of the first two
 #pragma unroll
   for (int k = 0; k < NR; ++k) {
     b1[k] = bg;
+    low1[k] = bg - band;
     j1[k] = kBg;
     b2[k] = b3[k] = -3.0e38f;
     j2[k] = kBg;
@@ -502,9 +504,12 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
               ty1 = ty0 + (kCell - 1);
   float tile_min[NR];  // wave-uniform: smallest b1 over the tile's pixels
   GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_pairs = 0, dg_upd = 0, dg_amb = 0, dg_walk = 0;)
+  bool dirty[NR];  // wave-uniform: some pixel's top three of radius k changed since tile_min[k] was taken
   auto refresh_tile_min = [&]() {
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
+      if (!dirty[k]) continue;
+      dirty[k] = false;
       unsigned m = valid ? ord_f32(b1[k]) : 0xffffffffu;
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
@@ -515,15 +520,26 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
       tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2_), umin_u32(c2, d2)));
     }
   };
+#pragma unroll
+  for (int k = 0; k < NR; ++k) dirty[k] = true;
   refresh_tile_min();
 
   const int cell_base = b * cells_y * cells_x;
   // the candidate ranges of the tile: rows nearest first, the own row as own cell / left / right
   auto row_range = [&](int step, int part, int &beg, int &end) -> bool {
-    const int cyy = cy + ((step & 1) ? -((step + 1) >> 1) : (step >> 1));
+    const int dyc = (step + 1) >> 1;  // row distance in cells
+    const int cyy = cy + ((step & 1) ? -dyc : dyc);
     if (cyy < 0 || cyy >= cells_y) return false;
-    const int c_lo = cx - ra.halo > 0 ? cx - ra.halo : 0;
-    const int c_hi = cx + ra.halo < cells_x - 1 ? cx + ra.halo : cells_x - 1;
+    // Cells of this row that the largest radius can reach from the tile: a cell dxc columns and dyc rows away is at
+    // least ((dxc - 1)+, (dyc - 1)+) * kCell pixels from every pixel of the tile (its points lie inside it, or --
+    // border cells -- beyond it), so the corner cells of the (2 halo + 1)^2 block drop out (4 of 25 at R = 10).
+    const float gy = (float)((dyc > 1 ? dyc - 1 : 0) * kCell);
+    const float rem = ra.s_max_all * 1.0001f - gy * gy;
+    if (rem < 0.f) return false;
+    int reach = (int)(__builtin_sqrtf(rem) * (1.0f / kCell)) + 1;
+    reach = reach < ra.halo ? reach : ra.halo;
+    const int c_lo = cx - reach > 0 ? cx - reach : 0;
+    const int c_hi = cx + reach < cells_x - 1 ? cx + reach : cells_x - 1;
     const int p_lo = step == 0 ? (part == 0 ? cx : (part == 1 ? c_lo : cx + 1)) : c_lo;
     const int p_hi = step == 0 ? (part == 0 ? cx : (part == 1 ? cx - 1 : c_hi)) : c_hi;
     if (p_lo > p_hi) return false;
@@ -582,10 +598,11 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
           for (int k = 0; k < NR; ++k) {
             if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
             const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
-            const float a = f * weight32(__builtin_fminf(s2 * ra.inv_r2[k], 1.0f));
-            const bool pass = ink && a >= b1[k] - band;
+            const float a = f * weight32(s2 * ra.inv_r2[k]);  // out of range: a finite value nobody looks at
+            const bool pass = ink && a >= low1[k];
             GDIAG(dg_pairs += __popcll(__ballot(ink)); dg_upd += __popcll(__ballot(pass));)
             if (__any(pass)) {
+              dirty[k] = true;
               if (pass) {
                 const bool first = a > b1[k], second = !first && a > b2[k], third = !first && !second && a > b3[k];
                 b3[k] = first || second ? b2[k] : (third ? a : b3[k]);
@@ -593,6 +610,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
                 j2[k] = first ? j1[k] : (second ? pos : j2[k]);
                 b1[k] = first ? a : b1[k];
                 j1[k] = first ? pos : j1[k];
+                low1[k] = b1[k] - band;
               }
             }
           }
