@@ -41,7 +41,7 @@ constexpr int kThreads = 256;     // element-wise kernels
 #ifndef SN_EMD_WAVES
 #define SN_EMD_WAVES 4
 #endif
-constexpr int kRankBins = 64;     // per cloud: counters of unassigned bidders per 1/64 of the Hilbert ranks
+constexpr int kRankBins = 256;    // per cloud: counters of unassigned bidders per 1/256 of the Hilbert ranks
 
 
 struct Top2 {
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int Rs = n / G, rs0 = m * Rs;  // static slice (final distances); n % 1024 == 0, G <= 64
-  const int binsize = n / kRankBins;   // ranks per counter bin (a multiple of 16)
+  const int binsize = n / kRankBins;   // ranks per counter bin (a multiple of 4: n % 1024 == 0)
   const int block_cnt = n / 1024;
   float *price = a.ws.price;
   int *flags = a.ws.flags;
@@ -1043,22 +1043,33 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
       // of the team derives the same split of the ranks into G contiguous, equally loaded ranges (bins are
       // indivisible).  A static split left the team waiting ~20 us per late iteration for the workgroup
       // whose region happened to hold two groups of bidders instead of one.
-      if (wave == 0) {
-        const int v = (int)__hip_atomic_load(reinterpret_cast<unsigned *>(a.ws.bins[cur] + b * kRankBins + lane),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int incl = v;
+      if (wave == 0) {  // lane l holds the bins 4 l .. 4 l + 3
+        const int2 lo2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane);
+        const int2 hi2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane + 2);
+        const int v[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
+        const int lsum = (v[0] + v[1]) + (v[2] + v[3]);
+        int incl = lsum;
         for (int d = 1; d < 64; d <<= 1) {
           const int t = __shfl_up(incl, d);
           if (lane >= d) incl += t;
         }
         const int total = __shfl(incl, 63);
-        int own = total > 0 ? (int)(((long long)(incl - v) * G) / total) : 0;
-        own = own < G - 1 ? own : G - 1;
-        const unsigned long long mine = __ballot(own == m);
+        // a bin goes to the workgroup its MIDPOINT falls to in the ideal split (boundaries land on the bin edge
+        // nearest to m total / G): with 256 bins a workgroup's load is within a couple of bidders of total / G,
+        // so that it needs a second group of 64 only when the ideal split does
+        int excl = incl - lsum, first = 0, cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int own = total > 0 ? (int)(((long long)(2 * excl + v[q]) * G) / (2LL * total)) : 0;
+          own = own < G - 1 ? own : G - 1;
+          first += __popcll(__ballot(own < m));
+          cnt += __popcll(__ballot(own == m));
+          excl += v[q];
+        }
         if (lane == 0) {
           s_range[0] = total;
-          s_range[1] = mine ? __builtin_ctzll(mine) * binsize : 0;
-          s_range[2] = __popcll(mine) * binsize;
+          s_range[1] = first * binsize;
+          s_range[2] = cnt * binsize;
         }
       }
       __syncthreads();
@@ -1071,8 +1082,8 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
         if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
       }
       // the counters Assign fills in this iteration (read last at the top of the previous one)
-      if (m == 0 && wave == 1)
-        stc(loc, a.ws.bins[cur ^ 1] + b * kRankBins + lane, 0);
+      if (m == 0 && tid >= 64 && tid < 64 + kRankBins)
+        stc(loc, a.ws.bins[cur ^ 1] + b * kRankBins + (tid - 64), 0);
       const bool dg = a.diag && team == 0 && tid == 0;
       long long tk = dg ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
       auto tick = [&](int slot) {

@@ -45,7 +45,7 @@ def test_argument_validation_without_gpu():
     assert lib.sn_mds(one, 1, 10, 20, one, one, null, ctypes.c_size_t(0), null) == -22
     lib.sn_emd_workspace_bytes.restype = ctypes.c_size_t
     ctl = 4 * (32 + 32 * 1024) + 8 * (16 + 64 * 64)   # persistent auction: barrier counters + diag words
-    assert lib.sn_emd_workspace_bytes(32, 16384) == (16 * 32 * 16384 * 4 + 2 * 32 * 64 * 4 + 2 * 32 * 16384 * 16 + 32 * 16384 * 8
+    assert lib.sn_emd_workspace_bytes(32, 16384) == (16 * 32 * 16384 * 4 + 2 * 32 * 256 * 4 + 2 * 32 * 16384 * 16 + 32 * 16384 * 8
                                                       + 2 * 32 * 4096 * 4 + 2 * 768 + 32 * 1024 * 32 + ctl)
 
 
