@@ -16,9 +16,10 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/p
 cd $R
 python - "$OUT" <<'PY'
 import csv, glob, json, sys
-kernels = ["emd_bid_kernel", "emd_auction_kernel", "emd_assign_kernel", "emd_compact_kernel", "emd_getmax_kernel",
-           "nn_search_kernel", "chamfer_bwd_scatter_kernel", "chamfer_bwd_own_kernel", "expansion_fwd_kernel",
-           "p2i_gather_max_kernel", "p2i_max_bwd_accum_kernel", "p2i_bin_scatter_kernel", "mds_clustered_kernel"]
+kernels = ["emd_auction_kernel", "emd_seed_kernel", "emd_init_kernel", "cloud_sort_count_kernel",
+           "nn_search_kernel", "chamfer_bwd_lists_kernel", "chamfer_bwd_gather_kernel", "expansion_fwd_kernel",
+           "p2i_gather_max_kernel", "p2i_max_bwd_accum_kernel", "p2i_bin_grouped_kernel", "p2i_absmax_kernel",
+           "depth_project_views_kernel", "mds_clustered_kernel"]
 res = {k: {} for k in kernels}
 for d in ("pmcA", "pmcB", "pmcC", "pmcD"):
     fs = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)
