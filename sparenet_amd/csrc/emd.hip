@@ -1163,11 +1163,21 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
       if (!team_barrier(ts, &s_flag)) return;
       tick(7);
       // ---- GetMax (emd_cuda.cu:181-194) for the own bidders
+      // a thread serves the same list slots in GetMax and in Assign: what it looked up for its FIRST slot (the
+      // only one once a workgroup has <= 1024 bidders) stays in registers across the barrier -- two dependent
+      // round trips less at the head of Assign
+      int keep_j = -1, keep_tgt = -1;
+      float keep_inc = 0.f;
       for (int u = tid; u < Um; u += kBidThreads) {
         const int j = ldc(&llist[u]);
         const int tgt = ldc(&bo.bid[o + j]);
+        const float bi = tgt < 0 ? 0.f : ldc(&bo.bid_inc[o + j]);
+        if (u == tid) {
+          keep_j = j;
+          keep_tgt = tgt;
+          keep_inc = bi;
+        }
         if (tgt < 0) continue;
-        const float bi = ldc(&bo.bid_inc[o + j]);
         const float mi = ldc(&bo.max_inc[o + tgt]);
         if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
           __hip_atomic_fetch_max(&bo.win[o + tgt], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1184,8 +1194,9 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
           atomicAdd(&s_bins[rank / binsize], 1);
         };
         for (int u = tid; u < Um; u += kBidThreads) {
-          const int j = ldc(&llist[u]);
-          const int tgt = ldc(&bo.bid[o + j]);
+          const bool kept = u == tid;
+          const int j = kept ? keep_j : ldc(&llist[u]);
+          const int tgt = kept ? keep_tgt : ldc(&bo.bid[o + j]);
           if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
             if (!last) raise(a.ws.rank1[o + j]);
             continue;
@@ -1208,7 +1219,7 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
             }
             stc(loc, &a.ws.assignment_inv[o + tgt], j);
             stc(loc, &a.assignment[o + j], tgt);
-            const float np = ldc(&price[o + tgt]) + ldc(&bo.bid_inc[o + j]);
+            const float np = ldc(&price[o + tgt]) + (kept ? keep_inc : ldc(&bo.bid_inc[o + j]));
             stc(loc, &price[o + tgt], np);
             const int pos = a.ws.rank2[o + tgt];  // the bid phase reads the price by stream position
             stc(loc, reinterpret_cast<float *>(a.ws.pk + o + pos), np);
