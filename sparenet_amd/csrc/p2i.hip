@@ -53,8 +53,29 @@ __device__ __forceinline__ Box box_of(float py, float px, int h, int w, float ra
   return b;
 }
 
+// The exact weight (float)(cos(pi r / R) / 2 + 1 / 2) with the cosine in double, as the reference evaluates it -- through
+// cos(pi t) = -sin(pi (t - 1/2)), t = r / R in [0, 1], and the sine's Taylor series on [-pi/2, pi/2] (12 terms,
+// within 2.3e-16 of the double cosine over the whole range: the library's cos() with its general range reduction
+// and the fp64 division in front of it were most of the gather's epilogue).  inv_radius = 1.0 / (double)R.
+__device__ __forceinline__ float cos_weight_inv(float r, double inv_radius) {
+  const double y = ((double)r * inv_radius - 0.5) * M_PI;
+  const double y2 = y * y;
+  double p = -3.868170170630684e-23;
+  p = __builtin_fma(p, y2, 1.9572941063391263e-20);
+  p = __builtin_fma(p, y2, -8.22063524662433e-18);
+  p = __builtin_fma(p, y2, 2.8114572543455206e-15);
+  p = __builtin_fma(p, y2, -7.647163731819816e-13);
+  p = __builtin_fma(p, y2, 1.6059043836821613e-10);
+  p = __builtin_fma(p, y2, -2.505210838544172e-08);
+  p = __builtin_fma(p, y2, 2.7557319223985893e-06);
+  p = __builtin_fma(p, y2, -0.0001984126984126984);
+  p = __builtin_fma(p, y2, 0.008333333333333333);
+  p = __builtin_fma(p, y2, -0.16666666666666666);
+  p = __builtin_fma(p, y2, 1.0);
+  return (float)(0.5 - 0.5 * (y * p));
+}
 __device__ __forceinline__ float cos_weight(float r, float radius) {
-  return (float)(cos((double)r * M_PI / (double)radius) * 0.5 + 0.5);
+  return cos_weight_inv(r, 1.0 / (double)radius);
 }
 
 __device__ __forceinline__ float sq2(float dx, float dy) {
@@ -621,14 +642,14 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   }
 
   // ---- exact values: the winner, the runner-up when it is inside the band, an exact walk when the third is too
-  auto exact_of = [&](unsigned pos, float radius, float s_max, float &v, unsigned &low) {
+  auto exact_of = [&](unsigned pos, double inv_radius, float s_max, float &v, unsigned &low) {
     // value and tie key (0xFFFFFFFE - id: larger = lower id) of the candidate at sorted position `pos`
     const float4 rec = srec[pos];
     const int pid = __float_as_int(rec.w);
     const float f = C1 ? rec.z : feat[(size_t)pid * channels + c];
     const float s2 = sq2(fx - rec.y, fy - rec.x);
     (void)s_max;
-    v = f * cos_weight(__builtin_sqrtf(s2), radius);
+    v = f * cos_weight_inv(__builtin_sqrtf(s2), inv_radius);
     low = 0xFFFFFFFEu - (unsigned)pid;
   };
   // output position: image b, radius k, channel c -> b * obstride + k * orstride + c * h * w (+ pixel): radius-major
@@ -638,6 +659,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   for (int k = 0; k < NR; ++k) {
     float best_v = bg;          // the reference replaces only on strictly greater: the background wins ties
     unsigned best_low = kBg;    // kBg = no point
+    const double inv_rd = 1.0 / (double)ra.radius[k];  // one value for every exact evaluation of this radius
     const bool walk = valid && b3[k] >= b1[k] - band;
     const bool amb = valid && !walk && b2[k] >= b1[k] - band;
     GDIAG(dg_amb += __popcll(__ballot(amb)); dg_walk += __popcll(__ballot(walk));)
@@ -646,7 +668,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
         if (pos == kBg) return;
         float v;
         unsigned low;
-        exact_of(pos, ra.radius[k], ra.s_max[k], v, low);
+        exact_of(pos, inv_rd, ra.s_max[k], v, low);
         if (v > best_v || (v == best_v && best_low != kBg && low > best_low)) {
           best_v = v;
           best_low = low;
@@ -667,7 +689,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
             if (walk && s2 <= ra.s_max[k]) {
               const int pid = __float_as_int(rec.w);
               const float f = C1 ? rec.z : feat[(size_t)pid * channels + c];
-              const float v = f * cos_weight(__builtin_sqrtf(s2), ra.radius[k]);
+              const float v = f * cos_weight_inv(__builtin_sqrtf(s2), inv_rd);
               const unsigned low = 0xFFFFFFFEu - (unsigned)pid;
               if (v > best_v || (v == best_v && best_low != kBg && low > best_low)) {
                 best_v = v;
