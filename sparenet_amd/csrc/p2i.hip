@@ -991,7 +991,14 @@ __device__ __forceinline__ double fixed_scale(const unsigned *absmax, float min_
   return ldexp(1.0, 43 - ilogbf(m));
 }
 
-constexpr int kAccSlots = 256;  // per-wave hash table: <= 64 pixels x 4 radii distinct winners
+#ifndef SN_ACC_SLOTS
+#define SN_ACC_SLOTS 128
+#endif
+constexpr int kAccSlots = SN_ACC_SLOTS;  // per-wave hash table.  A tile can have up to 64 x 4 distinct winners, real
+                                         // tiles have ~15: a term that finds no slot within kAccProbes steps goes
+                                         // straight to the global accumulators, and the smaller table (3.5 KB per
+                                         // wave instead of 7) lets 8 workgroups share a CU instead of 5
+constexpr int kAccProbes = 16;
 
 __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     const float *__restrict__ out_grad, const int *__restrict__ out_ids,
@@ -1044,15 +1051,28 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     const float fv = feat[(size_t)pid * channels + c];
     const float cf = gk * weight32(u);
     const float kk = gk * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
-    unsigned slot = ((unsigned)pid * 2654435761u) >> 24;  // 8 bits
-    for (;;) {  // <= 256 distinct winners per tile: the table cannot fill up
+    unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
+    bool found = false;
+    for (int probe = 0; probe < kAccProbes; ++probe) {
       const int prev = atomicCAS(&keys[wave][slot], -1, pid);
-      if (prev == -1 || prev == pid) break;
+      if (prev == -1 || prev == pid) {
+        found = true;
+        break;
+      }
       slot = (slot + 1) & (kAccSlots - 1);
     }
-    atomicAdd(&vals[wave][slot][0], (unsigned long long)llrint((double)cf * scale));
-    atomicAdd(&vals[wave][slot][1], (unsigned long long)llrint((double)(kk * dy) * scale));
-    atomicAdd(&vals[wave][slot][2], (unsigned long long)llrint((double)(kk * dx) * scale));
+    const unsigned long long t0 = (unsigned long long)llrint((double)cf * scale);
+    const unsigned long long t1 = (unsigned long long)llrint((double)(kk * dy) * scale);
+    const unsigned long long t2 = (unsigned long long)llrint((double)(kk * dx) * scale);
+    if (found) {
+      atomicAdd(&vals[wave][slot][0], t0);
+      atomicAdd(&vals[wave][slot][1], t1);
+      atomicAdd(&vals[wave][slot][2], t2);
+    } else {  // a crowded table: integer sums are exact in any order
+      atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)pid * channels + c), t0);
+      atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 0), t1);
+      atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 1), t2);
+    }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   for (int i = lane; i < kAccSlots; i += 64) {
