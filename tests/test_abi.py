@@ -87,3 +87,62 @@ def test_product_package_never_imports_the_oracle():
                 if re.search(r"^\s*(import|from)\s+oracle\b", txt, re.M) or "liboracle" in txt:
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def _split_top_level(argtext):
+    """Split a parenthesised argument text at top-level commas."""
+    parts, depth, cur = [], 0, ""
+    for ch in argtext:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return parts
+
+
+def _call_sites(src, name):
+    """Argument counts of every `name(` call in a Python source text."""
+    counts = []
+    for m in re.finditer(re.escape(name) + r"\s*\(", src):
+        i, depth = m.end(), 1
+        while depth and i < len(src):
+            depth += src[i] in "([{"
+            depth -= src[i] in ")]}"
+            i += 1
+        counts.append(len(_split_top_level(src[m.end():i - 1])))
+    return counts
+
+
+def test_every_python_call_passes_the_declared_number_of_arguments():
+    """ctypes does not check argument counts: a parameter added to the C entry point and forgotten at a call site
+    shifts every later argument silently.  Every `sn_*(...)` call in the package, bench.py and tools/ is counted
+    against the prototype in include/sparenet_hip.h."""
+    hdr = open(os.path.join(ROOT, "include", "sparenet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"^(?:int|size_t|void|long long|const char \*)\s*(sn_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", hdr,
+                         re.M | re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(_split_top_level(args))
+    assert len(protos) >= 40
+    checked = 0
+    for base in ("sparenet_amd", "tools", "."):
+        root = os.path.join(ROOT, base)
+        for dirpath, _, files in (os.walk(root) if base != "." else [(root, [], os.listdir(root))]):
+            for f in files:
+                if not f.endswith(".py"):
+                    continue
+                src = open(os.path.join(dirpath, f)).read()
+                for name, want in protos.items():
+                    for got in _call_sites(src, "." + name):
+                        # attribute access like `.sn_x.restype = ...` is not a call and is not matched (needs "(")
+                        assert got == want, f"{os.path.join(dirpath, f)}: {name} called with {got} arguments, declared {want}"
+                        checked += 1
+    assert checked >= 40
