@@ -1,0 +1,27 @@
+"""One GPU's share of an N-GPU STRONG-scaling step (B = 32 / N clouds), timed on one MI355X: predicts the strong
+curve the driver measures (the ops have no collective; the all-reduce of four floats is not included)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+hp = bench.HotPath(dev, [5.0, 7.0, 10.0])
+g = torch.Generator().manual_seed(1234)
+P = torch.rand(32, bench.N, 3, generator=g).to(dev)
+G = torch.rand(32, bench.N, 3, generator=g).to(dev)
+base = None
+for n in (1, 2, 4, 8):
+    b = 32 // n
+    pred, gt = P[:b].contiguous(), G[:b].contiguous()
+    for _ in range(5):
+        hp.step_overlapped(pred, gt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(30):
+        hp.step_overlapped(pred, gt)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 30 * 1e3
+    base = base or ms
+    print(f"N = {n}: {b:2d} clouds per GPU: {ms:.2f} ms per step -> speed-up {base / ms:.2f} of {n} ({base / ms / n:.0%})")
