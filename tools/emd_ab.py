@@ -42,7 +42,7 @@ for b in ((32,) if os.environ.get("AB_QUICK") else (32, 4, 1)):
         print(f"{mode}: B={b} iters={iters}: {e0.elapsed_time(e1)/5:.3f} ms per call", flush=True)
 
 if os.environ.get("SN_EMD_DIAG"):
-    for b in (32,):
+    for b in (int(os.environ.get("AB_DIAG_B", "32")),):   # AB_DIAG_B=4: the strong-scaling share of an 8-GPU job
         x, y = X[:b].to(dev), Y[:b].to(dev)
         _, _, ws = emd_forward_raw(x, y, 0.005, 50, return_workspace=True); torch.cuda.synchronize()
         _L.lib().sn_emd_diag_offset.restype = __import__("ctypes").c_size_t
