@@ -2,7 +2,8 @@
 """bench.py -- SpareNet loss/render hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either that very command -- it re-launches itself as N ranks -- or
+     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One "step" = one pass of the hot path over one synthetic batch (BASELINE.json configs[1] + configs[2]):
     Chamfer distance            fwd + bwd   [B,16384,3] <-> [B,16384,3]
@@ -11,11 +12,13 @@ One "step" = one pass of the hot path over one synthetic batch (BASELINE.json co
     ComputeDepthMaps render     fwd + bwd   8 views x radius_list, 256 x 256
     scalar losses               all-reduce (RCCL) when N > 1
 Scaling (whole clouds are independent, ranks own contiguous slices, no data-path collective):
-    --scaling weak   (default)  B = 32 clouds PER RANK, seed 1234 + rank
-    --scaling strong            ONE global batch of 32 clouds (seed 1234) split with dist_utils.shard:
-                                32 / N clouds per rank
+    --scaling strong (default)  ONE global batch of 32 clouds (seed 1234) split with dist_utils.shard:
+                                32 / N clouds per rank -- SURVEY 8(e)'s split, the north star's >= 6x question
+    --scaling weak              B = 32 clouds PER RANK, seed 1234 + rank (the same batch as strong at N = 1)
   At N > 1 the other mode is timed after the headline region with the same K / W and reported in
   `other_scaling`, so one driver run per N yields both curves.
+  `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run,
+  one process per GPU, RCCL); under a launcher (WORLD_SIZE set) it is one of the ranks.
 The four parts are independent given the predicted cloud; by default the renderer runs on a second
 HIP stream next to the distance losses (config.streams = 2; --no-overlap times the one-stream step).
 After the timed region the same steps run once more one stream at a time, untimed for `value`, to
@@ -27,10 +30,12 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
                     events on the main stream at the step boundaries)
   depthmaps_per_sec single-radius 256x256 maps per second over the same wall time
   roofline          the dominant kernel (emd_auction_kernel, one launch per EMD call): `achieved` / `frac` =
-                    algorithmic flops (14 per effective pair) / its launch time measured live with
-                    HIP events on the launch stream; `executed_*` = the work the kernel really issued
-                    (matrix-core + vector lane operations from committed PMC counters of the SAME build)
-                    over the same live time -- the pruned search skips most algorithmic pairs, so the two differ
+                    the work the kernel really ISSUED (matrix-core flops + vector lane operations from committed
+                    PMC counters of the SAME build) / its launch time measured live with HIP events on the launch
+                    stream, against the fp32 peak; `algorithmic_*` = SURVEY 8d's 14 flop x effective pairs over
+                    the same time (the pruned search skips most algorithmic pairs, so that rate can exceed the
+                    peak); `wait_frac`, `valu_busy`, `mfma_busy`, `traffic`; the same block for nn_search_kernel,
+                    p2i_gather_max_kernel and (other_ops) mds_clustered_kernel
   cpu_baseline      the CPU oracle (port of the reference algorithm; the Chamfer single-thread leg is the
                     reference's own CPU build when oracle/_ref is present) on a bounded sample, two legs
 """
@@ -62,6 +67,7 @@ IMG = 256
 N_VIEWS = 8
 FLOP_PER_PAIR = {"chamfer_fwd": 9.0, "emd_auction": 14.0}
 PEAK_F32_TFLOPS = 157.3                                       # MI355X_MICROARCH.md (vector == f32 MFMA peak)
+PEAK_HBM_GBS = 8000.0                                         # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 N_SIMD = 256 * 4
 
 
@@ -70,7 +76,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("auto", "weak", "strong"), default="auto",
+                    help="auto = strong: ONE global batch of 32 clouds split over the ranks (SURVEY 8e; at N = 1 "
+                         "both modes are the same 32-cloud workload); the other mode is reported in other_scaling")
     ap.add_argument("--radius-list", type=str, default="5,7,10",
                     help="p2i radii in pixels (reference default, configs/base_config.py:56-60); "
                          "BASELINE.json's literal 0.02,0.05 is near-empty in pixel units")
@@ -82,9 +90,37 @@ def parse():
                     help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
     ap.add_argument("--per-view-render", action="store_true",
                     help="render view by view (the reference's loop) instead of all 8 views in one pass")
+    ap.add_argument("--no-literal-radii", action="store_true",
+                    help="skip the second timed region with BASELINE.json's literal radius_list [0.02, 0.05]")
     ap.add_argument("--no-other-scaling", action="store_true",
                     help="N > 1: skip the second timed region with the other scaling mode")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.scaling == "auto":
+        args.scaling = "strong"
+    return args
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, one process
+    per GPU (the reference spreads a batch over its GPUs from one command too: runners/base_runner.py:100-104,
+    runners/sparenet_runner.py:32-34 -- nn.DataParallel threads there, torch.distributed.run + RCCL here)."""
+    import socket
+    import subprocess
+
+    shared = os.environ.get("BENCH_DEBUG_SHARED_GPU") == "1"
+    have = torch.cuda.device_count()
+    if have < args.gpus and not shared:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible; refusing to run fewer ranks "
+                         "than asked (BENCH_DEBUG_SHARED_GPU=1 puts all ranks on one GPU over gloo, for debugging)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def make_inputs(dev, rank, world, scaling):
@@ -414,23 +450,47 @@ def committed_counters(build_id, kernel):
     return best
 
 
+def device_identity(dev):
+    """Something that tells two GPUs apart: the UUID where torch exposes it, else the PCI location."""
+    pr = torch.cuda.get_device_properties(dev)
+    u = getattr(pr, "uuid", None)
+    if u is not None:
+        return str(u)
+    return "pci-%s:%s:%s" % tuple(getattr(pr, k, "?") for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+
+
 def main():
     args = parse()
     radius_list = [float(r) for r in args.radius_list.split(",")]
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)           # does not return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     shared = os.environ.get("BENCH_DEBUG_SHARED_GPU") == "1"   # debugging aid: N ranks on ONE GPU over gloo
     if shared:
         local = 0
+    elif local >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)   # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
+        ids = [None] * world
+        dist.all_gather_object(ids, device_identity(dev))
+        rccl_ranks = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "devices": ids,
+                      "distinct_devices": len(set(ids))}
+        if not shared and len(set(ids)) != world:
+            raise SystemExit(f"bench.py: {world} ranks but only {len(set(ids))} distinct GPUs: {ids}")
     if B % world:
         raise SystemExit(f"the strong split shards {B} clouds: world size {world} must divide it")
 
@@ -458,7 +518,7 @@ def main():
 
     def read_kernels():
         ks = {}
-        for kname in ("chamfer_fwd", "emd_auction", "expansion_fwd", "p2i_max_splat"):
+        for kname in ("chamfer_fwd", "emd_auction", "expansion_fwd", "p2i_max_splat", "mds"):
             ms = ctypes.c_double(0.0)
             cnt = lib.sn_prof_read(kname.encode(), ctypes.byref(ms))
             ks[kname] = {"launches": int(cnt), "total_ms": ms.value,
@@ -513,6 +573,24 @@ def main():
         }
         del p2_, g2_
 
+    # BASELINE config 3's radius_list exactly as written ([0.02, 0.05]: sub-pixel in the renderer's pixel units, so
+    # the maps are near-empty) timed as the same whole step after the headline region (SURVEY 8d asks for both)
+    literal = None
+    lit_radii = [0.02, 0.05]
+    if not args.no_literal_radii and radius_list != lit_radii:
+        hp2 = HotPath(dev, lit_radii, args.per_view_render)
+        lsteps = min(args.steps, 20)
+        e3, ps3, _ = timed_region(hp2, pred, gt, lsteps, min(args.warmup, 3), overlap, barrier)
+        t3 = torch.tensor([e3], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t3, op=dist.ReduceOp.MAX)
+        literal = {"radius_list": lit_radii, "steps": lsteps, "ms_per_step": float(t3.item()) / lsteps * 1e3,
+                   "depthmaps_per_sec": b_local * N_VIEWS * len(lit_radii) * lsteps * world / float(t3.item()),
+                   "step_ms_percentiles_rank0": percentiles(ps3),
+                   "note": "the same step (CD + EMD + expansion + render, fwd + bwd) with BASELINE.json's literal "
+                           "radii; whole-job maps over the wall time of these steps"}
+        del hp2
+
     # per-segment times on rank 0 (torch events on the current stream)
     seg = {}
     for i in range(1, len(timers)):
@@ -522,6 +600,43 @@ def main():
         seg[name] = seg.get(name, 0.0) + timers[i - 1][1].elapsed_time(ev)
     seg = {k: v / iso_steps for k, v in seg.items()}
 
+    def counters_block(kname, launches, dur_s):
+        """Executed-work figures of `kname` from the committed PMC counters of THIS build (None-valued if there are
+        none), over the live launch time `dur_s` of `launches` launches."""
+        blk = {}
+        pmc = committed_counters(build_id, kname)
+        if not pmc:
+            blk["counters_from"] = (f"none: no profiles/*pmc*.json was taken on build {build_id} "
+                                    "(tools/pmc_all.sh); counters of other code are not quoted")
+            return blk
+        fname, c = pmc
+        m = lambda k: c.get(k, {}).get("mean")
+        mops, valu, gui = m("SQ_INSTS_VALU_MFMA_MOPS_F32"), m("SQ_INSTS_VALU"), m("GRBM_GUI_ACTIVE")
+        if valu is not None and launches and dur_s > 0:
+            ex = (mops or 0.0) * 512.0 + valu * 64.0          # matrix-core flops + vector lane operations per launch
+            ex_rate = ex * launches / dur_s / 1e12
+            blk["executed_flops_per_launch"] = ex
+            blk["executed_tflops"] = ex_rate
+            blk["executed_frac"] = ex_rate / PEAK_F32_TFLOPS
+        if gui:
+            simd_cycles = gui / 8.0 * N_SIMD          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            if m("SQ_ACTIVE_INST_VALU") is not None:
+                blk["valu_busy"] = m("SQ_ACTIVE_INST_VALU") * 4.0 / simd_cycles   # quad-cycles
+            if m("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
+                blk["mfma_busy"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles
+        if m("SQ_WAIT_ANY") is not None and m("SQ_WAVE_CYCLES"):
+            blk["wait_frac"] = m("SQ_WAIT_ANY") / m("SQ_WAVE_CYCLES")      # wave cycles spent waiting on a counter
+        if m("SQ_WAVES") is not None:
+            blk["waves_per_launch"] = m("SQ_WAVES")
+        if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
+            # KB per launch; x2 on FETCH_SIZE: the guide's gfx950 correction, calibrated for 16 B/lane streaming
+            # reads; for 4 / 8-byte coherent accesses see traffic_calibration (tools/probe/traffic_probe.hip)
+            blk["traffic"] = (2.0 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024.0
+            blk["traffic_fetch_bytes_raw"] = m("FETCH_SIZE") * 1024.0
+            blk["traffic_write_bytes_raw"] = m("WRITE_SIZE") * 1024.0
+        blk["counters_from"] = f"profiles/{fname} (build {build_id})"
+        return blk
+
     roofline = None
     if not args.no_roofline:
         auc = kernels["emd_auction"]
@@ -530,65 +645,71 @@ def main():
             flops = FLOP_PER_PAIR["emd_auction"] * pairs_rank                # this rank, algorithmic
             dur = auc["total_ms"] * 1e-3
             achieved = flops / dur / 1e12
+            cb = counters_block("emd_auction_kernel", auc["launches"], dur)
             roofline = {
-                "kernel": "emd_auction_kernel", "bound": "mfma", "achieved": achieved,
-                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_TFLOPS,
-                "algorithmic_frac": achieved / PEAK_F32_TFLOPS,
-                "traffic": None,
+                "kernel": "emd_auction_kernel", "bound": "mfma",
+                # the honest figure: work the kernel really ISSUED (matrix-core flops + vector lane operations,
+                # PMC of this build) over its live launch time, against the fp32 peak
+                "achieved": cb.get("executed_tflops"),
+                "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": cb.get("executed_frac"),
+                "traffic": cb.get("traffic"),
+                # SURVEY 8(d)'s accounting: 14 flop x effective pairs / launch time.  NOT a roofline fraction: the
+                # pruned search never evaluates most algorithmic pairs, so this rate can exceed the peak
+                "algorithmic_tflops": achieved, "algorithmic_frac": achieved / PEAK_F32_TFLOPS,
+                "algorithmic_bytes_per_launch": 32.0 * b_local * N,           # 24 B n in + 8 B n out
                 "timing": "live: HIP events on the launch stream inside the timed region (the renderer contends on "
                           "the second stream); `isolated` = the same launches one stream at a time",
-                "note": ("pairwise search: `achieved` = 14 flop x effective pairs (SURVEY 8d) / launch time, an "
-                         "ALGORITHMIC rate -- the kernel skips target blocks by bounding box and filters pairs on "
-                         "the fp32 matrix cores, so most algorithmic pairs are never evaluated and the rate is not "
-                         "bounded by the peak; `executed_frac` is the issued work over the same time. peak = f32 "
-                         "vector = f32 MFMA dense peak"),
+                "note": ("`achieved` / `frac` = executed work (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 + SQ_INSTS_VALU x 64 "
+                         "per launch, every vector instruction counted as 64 useful lanes) / live launch time / fp32 "
+                         "peak (vector = f32 MFMA dense peak); null when no counters of this build are committed. "
+                         "The kernel is latency bound (wait_frac), not pipe or HBM bound."),
                 "launches": auc["launches"], "avg_launch_us": auc["avg_us"],
                 "pairs_per_launch_avg": pairs_rank / auc["launches"],
             }
-            pmc = committed_counters(build_id, "emd_auction_kernel")
-            if pmc:
-                fname, c = pmc
-                m = lambda k: c.get(k, {}).get("mean")
-                mops, valu, gui = m("SQ_INSTS_VALU_MFMA_MOPS_F32"), m("SQ_INSTS_VALU"), m("GRBM_GUI_ACTIVE")
-                if mops is not None and valu is not None:
-                    ex = mops * 512.0 + valu * 64.0          # matrix-core flops + vector lane operations per launch
-                    ex_rate = ex * auc["launches"] / dur / 1e12
-                    roofline["executed_flops_per_launch"] = ex
-                    roofline["executed_tflops"] = ex_rate
-                    roofline["executed_frac"] = ex_rate / PEAK_F32_TFLOPS
-                if gui:
-                    simd_cycles = gui / 8.0 * N_SIMD          # GRBM_GUI_ACTIVE is summed over the 8 XCDs
-                    if m("SQ_ACTIVE_INST_VALU") is not None:
-                        roofline["valu_busy"] = m("SQ_ACTIVE_INST_VALU") * 4.0 / simd_cycles   # quad-cycles
-                    if m("SQ_VALU_MFMA_BUSY_CYCLES") is not None:
-                        roofline["mfma_busy"] = m("SQ_VALU_MFMA_BUSY_CYCLES") / simd_cycles
-                if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
-                    # KB per launch; x2 on FETCH_SIZE: the guide's gfx950 correction for wide coalesced reads
-                    roofline["traffic"] = (2.0 * m("FETCH_SIZE") + m("WRITE_SIZE")) * 1024.0
-                roofline["counters_from"] = f"profiles/{fname} (build {build_id})"
-            else:
-                roofline["counters_from"] = (f"none: no profiles/*pmc*.json was taken on build {build_id} "
-                                             "(tools/pmc_all.sh); counters of other code are not quoted")
+            roofline.update({k: v for k, v in cb.items() if k not in ("traffic",)})
             iso = kernels_isolated.get("emd_auction")
             if iso and iso["launches"]:
                 ach = (FLOP_PER_PAIR["emd_auction"] * pairs_rank / args.steps * iso_steps
                        / (iso["total_ms"] * 1e-3) / 1e12)
-                roofline["isolated"] = {"achieved": ach, "frac": ach / PEAK_F32_TFLOPS,
+                roofline["isolated"] = {"algorithmic_tflops": ach, "algorithmic_frac": ach / PEAK_F32_TFLOPS,
                                         "avg_launch_us": iso["avg_us"]}
+                if cb.get("executed_flops_per_launch"):
+                    r = cb["executed_flops_per_launch"] / (iso["avg_us"] * 1e-6) / 1e12
+                    roofline["isolated"]["achieved"] = r
+                    roofline["isolated"]["frac"] = r / PEAK_F32_TFLOPS
             cf = kernels["chamfer_fwd"]
             if cf["launches"]:
                 a = (FLOP_PER_PAIR["chamfer_fwd"] * 2.0 * b_local * N * N * cf["launches"]
                      / (cf["total_ms"] * 1e-3) / 1e12)
-                roofline["chamfer_fwd"] = {"achieved": a, "algorithmic_frac": a / PEAK_F32_TFLOPS,
-                                           "avg_launch_us": cf["avg_us"],
-                                           "note": "sort + box-pruned search: 9 flop x ALL n*m pairs / launch time"}
+                blk = {"algorithmic_tflops": a, "algorithmic_frac": a / PEAK_F32_TFLOPS,
+                       "avg_launch_us": cf["avg_us"],
+                       "note": "sort + box-pruned search: 9 flop x ALL n*m pairs / launch time (algorithmic)"}
+                blk.update(counters_block("nn_search_kernel", cf["launches"], cf["total_ms"] * 1e-3))
+                if "executed_frac" in blk:
+                    blk["frac"] = blk["executed_frac"]
+                roofline["chamfer_fwd"] = blk
+            # the renderer's dominant kernel: HBM-roofline accounting of SURVEY 8(d) (12 B N in per view + 8 B S^2
+            # out per view and radius) next to what binds it in fact (vector-instruction issue: valu_busy)
+            gk = kernels.get("p2i_max_splat")
+            if gk and gk["launches"]:
+                views = 1 if args.per_view_render else N_VIEWS
+                byts = views * 12.0 * b_local * N + views * len(radius_list) * 8.0 * b_local * IMG * IMG
+                rate = byts * gk["launches"] / (gk["total_ms"] * 1e-3) / 1e9
+                blk = {"kernel": "p2i_gather_max_kernel", "bound": "hbm", "achieved": rate, "peak": PEAK_HBM_GBS,
+                       "unit": "GB/s", "frac": rate / PEAK_HBM_GBS, "algorithmic_bytes_per_launch": byts,
+                       "avg_launch_us": gk["avg_us"], "launches": gk["launches"],
+                       "note": "algorithmic bytes / live launch time; the kernel is bound by vector-instruction issue "
+                               "(valu_busy), not by HBM"}
+                blk.update(counters_block("p2i_gather_max_kernel", gk["launches"], gk["total_ms"] * 1e-3))
+                roofline["p2i_gather_max"] = blk
 
     if rank == 0:
         out = {
             "metric": "point-pairs/sec (CD+EMD) + depthmaps/sec, B=32 N=16384",
             "value": pairs_total / elapsed,
             "unit": "point-pairs/s",
-            "n_gpus": world,
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -598,6 +719,8 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "depthmaps_per_sec": maps_total / elapsed,
+            "depthmaps_per_sec_literal_radii": literal["depthmaps_per_sec"] if literal else None,
+            "literal_radii": literal,
             "step_ms_percentiles_rank0": percentiles(per_step),
             "config": {
                 "workload": (f"per rank: CD fwd+bwd + EMD(eps 0.005, 50 it) fwd+bwd + expansion(P=512, "
@@ -619,7 +742,24 @@ def main():
             "roofline": roofline,
         }
         if world == 1 and not args.no_other_ops:
-            out["other_ops_ms_rank0"] = other_ops(dev, pred, hp.last_mean_mst)
+            oo = other_ops(dev, pred, hp.last_mean_mst)
+            out["other_ops_ms_rank0"] = oo
+            if roofline is not None:
+                # the sampler (outside the headline step; 2 calls per generator forward): SURVEY 8(d)'s 12 flop per
+                # point and round, 16383 dependent rounds on ONE CU per cloud (B of 256 CUs busy) -- latency bound
+                fl = 12.0 * B * (N - 1) * 19384
+                blk = {"kernel": "mds_clustered_kernel", "bound": "valu_f32", "peak": PEAK_F32_TFLOPS,
+                       "unit": "TFLOP/s", "algorithmic_flops_per_launch": fl,
+                       "surface": {"ms": oo["mds_19384_to_16384_surface"],
+                                   "algorithmic_frac": fl / (oo["mds_19384_to_16384_surface"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
+                       "dense": {"ms": oo["mds_19384_to_16384"],
+                                 "algorithmic_frac": fl / (oo["mds_19384_to_16384"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
+                       "note": "one workgroup per cloud and one pick per round: per-round latency x 16383; the culled "
+                               "update skips most of the algorithmic point-rounds (surface regime)"}
+                cbm = counters_block("mds_clustered_kernel", 1, oo["mds_19384_to_16384_surface"] * 1e-3)
+                blk.update(cbm)
+                blk["frac"] = cbm.get("executed_frac")      # counters are taken on the surface-like cloud
+                roofline["mds_clustered"] = blk
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             # the north star's combined ratio: one step's forward work, CPU over the GPU's whole step

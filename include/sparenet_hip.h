@@ -34,7 +34,9 @@ extern "C" {
 #endif
 
 #define SN_EINVAL (-22)
-#define SN_ABI_VERSION 1
+/* a team barrier of an earlier persistent EMD launch on this device gave up (see sn_emd_forward) */
+#define SN_ETIMEDOUT (-110)
+#define SN_ABI_VERSION 3
 
 int sn_abi_version(void);
 /* hash of the HIP sources this library was built from (profiles/ measurements carry it) */
@@ -97,9 +99,21 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
  *               (effective pair evaluations); stats[1] += iterations that had
  *               at least one bidder (one atomic per cloud per iteration).
  * With SN_EMD_DIAG=1|2 in the environment the call also leaves phase timers of the first team
- * in the workspace, 16 + 64*64 int64 words at sn_emd_diag_offset (tools/emd_ab.py). */
+ * in the workspace, 16 + 64*64 int64 words at sn_emd_diag_offset (tools/emd_ab.py).
+ *
+ * Failure behaviour (the reference returns an error code from emd_cuda_forward, emd_cuda.cu:276-281): the
+ * auction is ONE persistent launch whose workgroups wait for each other; every wait is bounded (> 2 s).  If a
+ * barrier gives up (a CU withheld from the launch by another tenant or a debugger), every workgroup leaves,
+ * the unfinished clouds get dist = NaN and assignment = -1, and the NEXT sn_emd_forward / sn_emd_backward call
+ * on that device returns SN_ETIMEDOUT without a host synchronisation (SN_EMD_CHECK=1: the failing call itself
+ * synchronises and returns SN_EINVAL).
+ * Memory-model note: the launch hands data between workgroups with relaxed coherent accesses and no fences, and
+ * keeps the stores of a team that sits on one XCD in that XCD's L2.  This is gfx950 behaviour, verified once per
+ * device by a litmus kernel at the first call; on failure, or with SN_EMD_SAFE=1, the launch uses agent-scope
+ * release / acquire barriers and agent-scope stores instead (sn_emd_mode() reports which). */
 size_t sn_emd_workspace_bytes(int b, int n);
 size_t sn_emd_diag_offset(int b, int n);
+int sn_emd_mode(void);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,
                    void *workspace, size_t workspace_bytes,

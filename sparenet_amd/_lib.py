@@ -20,27 +20,63 @@ class SparenetHipError(RuntimeError):
     pass
 
 
+# The C ABI this Python side was written against (include/sparenet_hip.h: SN_ABI_VERSION).  The library is built
+# separately and is not tracked: a stale .so next to newer Python (or the reverse) would make ctypes pass shifted
+# arguments -- memory corruption instead of an error -- so lib() refuses any other version.
+EXPECTED_ABI = 3
+
+_CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+           "long long": ctypes.c_longlong, "long": ctypes.c_long, "unsigned": ctypes.c_uint, "void": None}
+
+
+def _prototypes():
+    """{name: (restype, [argtypes])} parsed from include/sparenet_hip.h, or {} when the header is not shipped
+    next to the package (the version check above still applies)."""
+    import re
+
+    hdr = os.path.join(os.path.dirname(_HERE), "include", "sparenet_hip.h")
+    if not os.path.isfile(hdr):
+        return {}
+    txt = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"^(int|size_t|void|long long|const char \*)\s*(sn_[a-z0-9_]+)\s*\(([^;]*?)\)\s*;", txt,
+                         re.M | re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        types = []
+        if args not in ("", "void"):
+            for a in args.split(","):
+                a = " ".join(a.split())
+                if "*" in a:
+                    types.append(ctypes.c_char_p if a.startswith("const char") else ctypes.c_void_p)
+                else:
+                    base = a.rsplit(" ", 1)[0].replace("const ", "").strip()
+                    types.append(_CTYPES[base])
+        out[name] = (ctypes.c_char_p if "char" in ret else _CTYPES[ret], types)
+    return out
+
+
 def lib():
-    """Load (once) and return the HIP library; raises if it is not built."""
+    """Load (once) and return the HIP library; raises if it is not built or was built for another ABI."""
     global _lib
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
             raise SparenetHipError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C sparenet_amd/csrc`. sparenet_amd has no CPU fallback.")
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.sn_last_error.restype = ctypes.c_char_p
-        _lib.sn_build_id.restype = ctypes.c_char_p
-        _lib.sn_prof_read.restype = ctypes.c_longlong
-        _lib.sn_prof_enable.restype = None
-        _lib.sn_prof_reset.restype = None
-        for name in ("sn_emd_workspace_bytes", "sn_emd_diag_offset", "sn_p2i_max_workspace_bytes",
-                     "sn_depthmaps_workspace_bytes", "sn_expansion_workspace_bytes", "sn_mds_workspace_bytes", "sn_p2i_max_backward_workspace_bytes",
-                     "sn_p2i_max_multi_workspace_bytes",
-                     "sn_p2i_max_backward_multi_workspace_bytes", "sn_chamfer_workspace_bytes", "sn_chamfer_backward_workspace_bytes", "sn_p2i_f64_workspace_bytes",
-                     "sn_graph_feature_backward_workspace_bytes", "sn_knn_workspace_bytes"):
-            if hasattr(_lib, name):
-                getattr(_lib, name).restype = ctypes.c_size_t
+        L = ctypes.CDLL(LIB_PATH)
+        got = L.sn_abi_version()
+        if got != EXPECTED_ABI:
+            raise SparenetHipError(
+                f"{LIB_PATH} implements C ABI version {got}, this Python side needs {EXPECTED_ABI}: rebuild the "
+                "library (`make -C sparenet_amd/csrc`)")
+        L.sn_last_error.restype = ctypes.c_char_p
+        L.sn_build_id.restype = ctypes.c_char_p
+        for name, (ret, args) in _prototypes().items():
+            fn = getattr(L, name, None)
+            if fn is not None:      # a missing export is test_abi's finding, not a load-time failure
+                fn.restype = ret
+                fn.argtypes = args
+        _lib = L
     return _lib
 
 

@@ -29,8 +29,12 @@
 //   * bidders are served in Hilbert order, 64 neighbours per group, S = 2^k <= 16 waves of a workgroup
 //     sharing a group (each takes the superblocks sb with sb mod S == its segment); superblocks and
 //     16-target blocks outside the reach of the group's filters are skipped by bounding box.
-//   * GetMax: deterministic atomicMax of the bidder index inside the window.
+//   * GetMax + Assign are ONE target-centric phase: the bid epilogue links the bidders of a target into a list
+//     (atomic exchange on the target's head word); after ONE team barrier the list's head walks it, applies the
+//     reference's +-1e-6 window and its highest-bidder-index rule, awards the target and re-flags the losers.
+//     Two team barriers per iteration instead of three, no separate GetMax pass.
 #include <cstdlib>
+#include <mutex>
 
 #include "cloud_sort.hpp"
 #include "common.hpp"
@@ -180,6 +184,13 @@ __device__ __forceinline__ void stc(bool loc, int *p, int v) {
 __device__ __forceinline__ void stc(bool loc, float *p, float v) {
   stc(loc, reinterpret_cast<int *>(p), __float_as_int(v));
 }
+__device__ __forceinline__ void stc2(bool loc, int *p, int x, int y) {  // 8-byte aligned pair, one store
+  const unsigned long long v = (unsigned long long)(unsigned)x | ((unsigned long long)(unsigned)y << 32);
+  if (loc)
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // {price, target index} of a stream position: ONE coherent 8-byte load (the price changes inside the launch)
 __device__ __forceinline__ float2 ldc_pk(const float2 *p) {
   const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
@@ -211,11 +222,11 @@ struct EmdWs {
   int *assignment_inv;
   float *price;
   int *bid, *bid2;
-  float *bid_inc;
+  int *rec;      // [B, n, 2] by bidder RANK: {bid increment bits, rank of the next bidder of the same target or -1}
   float *max_inc;
-  int *max_idx;  // GetMax's winner per target; PERSISTS across iterations like the reference's tensor
-  int *win;      // this iteration's in-window winner per target (-1: nobody was in the window)
-  int *list[1];  // the unassigned bidders of the iteration, per workgroup in its own rank range
+  int *max_idx;  // GetMax's winner per target (as a bidder RANK); PERSISTS across iterations like the reference's tensor
+  int *head;     // [B, n] per target: rank of the bidder that pushed last in this iteration's bid phase, -1: no bid
+  int *list[1];  // [B, n, 2] the unassigned bidders of the iteration as {index, rank}, per workgroup in its own rank range
   float *prt;    // [B, n/64, 16, 4] prices by stream position, transposed for the coarse filter (see bid_group)
   int *bins[2];  // [B, 64] ping-pong: flagged (= unassigned) bidders per 1/64 of the rank range
   f4 *t4s;       // [B, n] by stream position p: {x, y, z, index bits} of target tperm[p] (constant in the launch)
@@ -245,11 +256,10 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.assignment_inv[e] = -1;
     ws.price[e] = 0.f;
     ws.max_inc[e] = 0.f;  // emd_module.py:49 (zeros, not -1e9)
-    ws.max_idx[e] = 0;
+    ws.head[e] = -1;
     ws.bid[e] = -1;   // no previous favourites yet (filter seeding)
     ws.bid2[e] = -1;
-    ws.list[0][e] = ws.perm1[e];  // Morton order: 64 consecutive bidders are neighbours
-    ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);
+    ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);  // max_idx: see emd_seed_kernel (needs rank1 complete)
     ws.flags[e] = 1;  // every bidder starts flagged (= unassigned)
     ws.prt[e] = 0.f;
     {  // stream position p of this cloud holds target k = tperm[p]
@@ -367,34 +377,51 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
     }
     ws.bid[je] = k1;
     ws.bid2[je] = k2;
+    // the reference's max_idx tensor starts as zeros = "bidder 0" (emd_module.py:50); kept here as a RANK
+    ws.max_idx[e] = ws.rank1[bb * n];
   }
 }
 
 struct BidOut {
   int *bid, *bid2;
-  float *bid_inc, *max_inc;
-  int *win;
+  int *rec;
+  float *max_inc;
+  int *head;
   bool loc;  // the team sits on one XCD: plain stores (see stc)
 };
 
 constexpr int kBidWaves = 16;
 constexpr int kBidThreads = kBidWaves * 64;
+constexpr int kStash = 1024;  // list slots whose bid is handed to the award phase through LDS
 
-__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, const Top2 &top,
-                                         float eps) {
+// What the award phase needs to know about the bid of list slot u (written by the wave that emits the bid, read
+// after the team barrier by thread u): saves the llist -> bid -> rec chain of dependent coherent loads.
+struct BidStash {
+  int tgt, rank, inc_bits, next;
+};
+
+// The bid of bidder j (Morton rank `rank`, list slot u).  Besides the favourites (next iteration's filter seeds)
+// and the running maximum of the target's increments (emd_cuda.cu:175-177), the bidder LINKS itself into the
+// list of its target: head[target] <- rank, rec[rank] = {increment, previous head}.  After the team barrier the
+// bidder that finds itself at the head walks the list (award phase of the kernel).
+__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int rank, int u, BidStash *stash,
+                                         const Top2 &top, float eps) {
   const bool loc = A.loc;
   if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
     stc(loc, &A.bid[o + j], -1);
     stc(loc, &A.bid2[o + j], -1);
-    stc(loc, &A.bid_inc[o + j], 0.f);
+    stc2(loc, &A.rec[2 * (o + rank)], 0, -1);
+    if (u < kStash) stash[u] = BidStash{-1, rank, 0, -1};
     return;
   }
   const float inc = (top.best - top.better) + eps;
   stc(loc, &A.bid[o + j], top.best_i);
   stc(loc, &A.bid2[o + j], top.better_i == top.best_i ? -1 : top.better_i);
-  stc(loc, &A.bid_inc[o + j], inc);
   atomic_max_float(&A.max_inc[o + top.best_i], inc);
-  stc(loc, &A.win[o + top.best_i], -1);  // this iteration's winner is derived in the GetMax phase
+  const int prev = (int)__hip_atomic_exchange(reinterpret_cast<unsigned *>(&A.head[o + top.best_i]), (unsigned)rank,
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  stc2(loc, &A.rec[2 * (o + rank)], __float_as_int(inc), prev);
+  if (u < kStash) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), prev};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -464,7 +491,7 @@ struct GroupAcc {  // per bidder group of a workgroup: the arrival-order merge o
   // two previous favourites: four dependent gathers).  Sixteen waves each doing these lookups for the same 64
   // bidders put 16 x 12 x 64 scattered requests on the CU's address unit per iteration: 3.1 us of every bid phase.
   float sx[64], sy[64], sz[64], scm[64];
-  int sj[64];
+  int sj[64], sr[64];
 };
 
 // level-1 threshold T' of one bidder: base = slack - |x|^2 is fixed, cm grows
@@ -512,19 +539,29 @@ struct TeamGeom {
   int xcd;     // 1: a team = G consecutive tickets of one XCD's counter (XCD-local teams)
 };
 
-__host__ __device__ inline TeamGeom team_geometry(int B, int W) {
+// W workgroups (one per CU) are split into teams of G; team t serves the clouds t, t + teams, ...
+//   * XCD-local geometry (W a multiple of 64: 8 XCDs x W/8 CUs): a team lives on ONE XCD -- its barrier counter,
+//     flags, bids and prices stay in that XCD's L2 (plain stores, see stc) and a barrier costs ~1.1 us.  Each XCD
+//     hosts ceil(B / 8) teams of G = 2^k <= (W/8) / ceil(B/8) workgroups.  With fewer than 8 clouds some XCDs
+//     idle: a late iteration is bound by the per-workgroup latency chain, not by the number of workgroups, and
+//     the cross-XCD team of 64 it replaces paid 2.7 us per barrier and coherent (fabric) stores.
+//   * otherwise (other partition modes, small devices): contiguous teams from one global counter.
+// gmax: upper bound on G (SN_EMD_G, experiments); legacy != 0: round 2's geometry (SN_EMD_GEOM=1).
+__host__ __device__ inline TeamGeom team_geometry(int B, int W, int gmax = 64, int legacy = 0) {
   TeamGeom t;
-  if (B >= 32 && W >= 64) {
-    // one XCD's share of a block of 64 tickets per team; more clouds than teams: halve the teams' size
-    // until every cloud has its own team (teams of one workgroup serve several clouds in turn)
-    int g = 8;
-    while (g > 1 && (W / (8 * g)) * 8 < B) g >>= 1;
+  const bool xcd_ok = W >= 64 && W % 64 == 0;
+  if (xcd_ok && (B >= 32 || !legacy)) {
+    const int per = W / 8;                 // workgroups of one XCD
+    const int tpx = (B + 7) / 8;           // teams an XCD must host so that every cloud has its own
+    int g = 1;
+    while (g * 2 * tpx <= per && g * 2 <= gmax) g *= 2;
     t.G = g;
-    t.teams = (W / (8 * g)) * 8;
+    t.teams = (per / g) * 8;
     t.xcd = 1;
   } else {
     int g = 1;
-    while (g < 64 && g * 2 * B <= W) g *= 2;
+    while (g < 64 && g * 2 * B <= W && g * 2 <= gmax) g *= 2;
+    if (W < 128) g = 1;  // two concurrent launches may each hold up to G - 1 workgroups waiting: never on a small device
     t.G = g;
     t.teams = W / g > 0 ? W / g : 1;
     t.xcd = 0;
@@ -537,17 +574,24 @@ constexpr unsigned kSpinLimit = 40u * 1000u * 1000u;  // x ~64 ns: > 2 s
 struct TeamSync {
   unsigned *bar;     // the team's counter
   unsigned *abort;   // the launch's abort word
+  unsigned *sticky;  // the device's sticky error word (host-visible; sn_emd_* report it at their next call)
   unsigned target;   // arrivals expected at the next barrier
+  unsigned limit;    // spins before a barrier gives up
   int G;
+  int fenced;        // 1: agent-scope release / acquire around the barrier (SN_EMD_SAFE or a failed self-test)
 };
 
-// All waves of all G workgroups arrive.  No fence: every word a phase hands to the next one is written and
-// read through the coherent accessors above (ldc / stc / atomics); each wave drains its stores
+// All waves of all G workgroups arrive.  No fence by default: every word a phase hands to the next one is written
+// and read through the coherent accessors above (ldc / stc / atomics); each wave drains its stores
 // (s_waitcnt vmcnt(0)) before its workgroup arrives, the arrival counter is a device-scope atomic.
 // Measured: 1.1 us per barrier instead of 3.7 us with an agent-scope release + acquire pair, and the phases
-// after it no longer start with an invalidated L1 / L2.
+// after it no longer start with an invalidated L1 / L2.  This relies on gfx950's cache behaviour (write-through
+// L1, sc1 accesses meeting in the L2 / at the fabric), which the HIP memory model does not promise: the library
+// verifies it once per device with a litmus kernel (emd_litmus_kernel) and falls back to `fenced` barriers +
+// agent-scope stores when the check fails or SN_EMD_SAFE=1 is set.
 __device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
   ts.target += (unsigned)ts.G;
   if (threadIdx.x == 0) {
@@ -558,8 +602,9 @@ __device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 255u) == 0u) {
         if (__hip_atomic_load(ts.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 0; break; }
-        if (spins > kSpinLimit) {
+        if (spins > ts.limit) {
           __hip_atomic_store(ts.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (ts.sticky) __hip_atomic_store(ts.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
           ok = 0;
           break;
         }
@@ -568,6 +613,7 @@ __device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
     *s_flag = ok;
   }
   __syncthreads();
+  if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return *s_flag != 0;
 }
 
@@ -584,6 +630,7 @@ struct BidCtx {
   const f4 *prt;     // prices of this cloud, transposed (plain loads on purpose: see below); nullptr: not used
   const float *sbb;  // block boxes of this cloud
   BidOut A;
+  BidStash *stash;   // LDS, kStash entries
 #ifdef SN_BID_STAMPS
   long long *stamps;  // experiment build: per-wave time per part of bid_group (100 MHz ticks), or nullptr
 #endif
@@ -611,7 +658,8 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
 #define COUNT(i)
 #endif
   if (grp < ngroups && seg == 0) {  // wave-uniform: the group's first wave looks its bidders up
-    const int jj = ldc(&lst[active ? u : grp * 64]);
+    const int2 jr = ldc2(&lst[2 * (active ? u : grp * 64)]);  // {bidder index, Morton rank}
+    const int jj = jr.x;
     const float x1 = c.p1[jj * 3 + 0], y1 = c.p1[jj * 3 + 1], z1 = c.p1[jj * 3 + 2];
     float cm = -1e9f;
     const int pa = ldc(&c.A.bid[c.o + jj]), pb = ldc(&c.A.bid2[c.o + jj]);
@@ -627,6 +675,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
     ga.sz[lane] = z1;
     ga.scm[lane] = cm;
     ga.sj[lane] = jj;
+    ga.sr[lane] = jr.y;
   }
   __syncthreads();  // every wave of the workgroup calls bid_group the same number of times
   if (grp < ngroups) {  // wave-uniform
@@ -919,7 +968,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       atomicExch(&ga.lock, 0);
     }
   }
-  if (emit && active) emit_bid(c.A, c.o, j, top, c.eps);
+  if (emit && active) emit_bid(c.A, c.o, j, ga.sr[lane], u, c.stash, top, c.eps);
 #ifdef SN_BID_STAMPS
   STAMP(4)
   if (c.stamps && lane == 0)
@@ -935,18 +984,23 @@ struct AuctionArgs {
   float *dist;
   EmdWs ws;
   AuctionCtl *ctl;
+  unsigned *sticky;   // host-visible per-device error word (nullptr: none)
+  unsigned spin_limit;
+  int safe;           // 1: fenced barriers + agent-scope stores only (SN_EMD_SAFE / failed self-test)
   long long *stats;
   TeamGeom tg;
   int diag;  // SN_EMD_DIAG (tools/emd_ab.py): dwords[4..11] += 100 MHz ticks of team 0 / workgroup 0 per phase
-             // (compact, -, bid, barrier, getmax, barrier, assign, barrier); 2: also per iteration and
+             // (compact, -, bid, barrier, award, barrier, -, -); 2: also per iteration and
              // workgroup at dwords[16 + ((it * 8 + m) * 8 + phase)].  dwords = the diag area of the workspace
-             // (sn_emd_diag_offset), zeroed by the call.
+             // (sn_emd_diag_offset), zeroed by the call.  Bit 2 (4): every team a mixed-XCD one; bit 3 (8): the
+             // second workgroup of team 0 leaves at once and barriers give up early (tests the time-out path).
   long long *dwords;
 };
 
 __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(AuctionArgs a) {
   __shared__ WaveTab tabs[kBidWaves];
   __shared__ GroupAcc gacc[kBidWaves];
+  __shared__ BidStash stash[kStash];
   __shared__ int wsum[kBidWaves];
   __shared__ int s_flag, s_ticket, s_stray, s_range[3], s_bins[kRankBins];
   const int tid = threadIdx.x;
@@ -980,29 +1034,52 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
     }
     s_ticket = t;
     s_stray = stray;
+    s_flag = __hip_atomic_load(&a.ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;  // a late starter
   }
   __syncthreads();
+  const bool late = s_flag != 0;  // one read for the whole workgroup: the branch below must be uniform
   const int ticket = s_ticket;
   if (ticket < 0) return;  // no slot left: surplus workgroup of a grid larger than teams x G
   const int team = ticket / G, m = ticket % G;
-  if (team >= a.tg.teams) return;
-  TeamSync ts = {a.ctl->bar + (size_t)team * 32, &a.ctl->abort, 0u, G};
+  if (team >= a.tg.teams || team >= a.B) return;  // a team without a cloud (fewer clouds than teams)
+  if ((a.diag & 8) && ticket == 1) return;        // test knob: a team member that never arrives
+  const int n = a.n, nsb = n >> 6;
+  TeamSync ts = {a.ctl->bar + (size_t)team * 32, &a.ctl->abort, a.sticky, 0u, a.spin_limit, G, a.safe};
+  // A barrier gave up (a team member never arrived within the spin limit: the device is shared with something that
+  // keeps a CU from this launch, or a debugger): every workgroup of the launch leaves.  What it leaves behind must
+  // not look like a result: the clouds this team had not finished get NaN distances and -1 assignments, the
+  // device's sticky word makes the next sn_emd_* call fail (the reference returns an error code there,
+  // emd_cuda.cu:276-281).
+  auto bail = [&](int b_from) {
+    for (int b = b_from; b < a.B; b += a.tg.teams)
+      for (int e = tid; e < n; e += kBidThreads) {
+        a.dist[(size_t)b * n + e] = __builtin_nanf("");
+        a.assignment[(size_t)b * n + e] = -1;
+      }
+  };
+  if (late) {  // the launch was given up before this workgroup started
+    bail(team);
+    return;
+  }
   // Is the whole team on ONE XCD?  Then its stores may stay in that XCD's L2 (see stc).  Every member that took
   // a slot of another XCD's team says so in the team's second control word; one formation barrier later every
-  // member reads the same answer.  Teams that span XCDs by design (fewer than 32 clouds) never qualify.
+  // member reads the same answer.
   bool loc = false;
   if (a.tg.xcd) {
     unsigned *mixed = a.ctl->bar + (size_t)team * 32 + 1;
     if (G > 1) {
       if (tid == 0 && s_stray) __hip_atomic_fetch_or(mixed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!team_barrier(ts, &s_flag)) return;
+      if (!team_barrier(ts, &s_flag)) {
+        bail(team);
+        return;
+      }
       loc = __hip_atomic_load(mixed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
     } else {
       loc = true;  // a team of one workgroup
     }
   }
+  if (a.safe) loc = false;
 
-  const int n = a.n, nsb = n >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
   const int Rs = n / G, rs0 = m * Rs;  // static slice (final distances); n % 1024 == 0, G <= 64
@@ -1011,7 +1088,7 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
   float *price = a.ws.price;
   int *flags = a.ws.flags;
   int *llist_all = a.ws.list[0];
-  const BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.bid_inc, a.ws.max_inc, a.ws.win, loc};
+  const BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc};
   if (a.diag && m == 0 && tid == 0 && loc) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + 12, 1ull);  // teams on one XCD
 
   for (int b = team; b < a.B; b += a.tg.teams) {
@@ -1036,10 +1113,12 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
     c.ms = a.ws.mstream + (size_t)b * nsb * 64;
     c.sbb = a.ws.sbbox + (size_t)b * nsb * 32;
     c.A = bo;
+    c.stash = stash;
+    const int *perm1 = a.ws.perm1 + o;
 
     for (int it = 0; it < a.iters; ++it) {
       const int cur = it & 1;
-      // The unassigned bidders per 1/64 of the rank range, counted by the previous Assign: every workgroup
+      // The unassigned bidders per 1/256 of the rank range, counted by the previous award phase: every workgroup
       // of the team derives the same split of the ranks into G contiguous, equally loaded ranges (bins are
       // indivisible).  A static split left the team waiting ~20 us per late iteration for the workgroup
       // whose region happened to hold two groups of bidders instead of one.
@@ -1075,13 +1154,13 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
       __syncthreads();
       const int U = s_range[0], r0 = s_range[1], R = s_range[2];
       if (U == 0) break;  // every workgroup of the team reads the same value
-      int *llist = llist_all + o + r0;
+      int *llist = llist_all + 2 * (o + r0);   // {index, rank} pairs
       const bool last = it == a.iters - 1;
       if (m == 0 && tid == 0 && a.stats) {
         atomicAdd(reinterpret_cast<unsigned long long *>(a.stats), (unsigned long long)U * n);
         if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
       }
-      // the counters Assign fills in this iteration (read last at the top of the previous one)
+      // the counters the award phase fills in this iteration (read last at the top of the previous one)
       if (m == 0 && tid >= 64 && tid < 64 + kRankBins)
         stc(loc, a.ws.bins[cur ^ 1] + b * kRankBins + (tid - 64), 0);
       const bool dg = a.diag && team == 0 && tid == 0;
@@ -1105,10 +1184,8 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
           if (w < vec) {  // coherent reads (other workgroups raised these flags), two 8-byte words per lane
             const int2 lo2 = ldc2(flags + o + r0 + 4 * w), hi2 = ldc2(flags + o + r0 + 4 * w + 2);
             f = make_int4(lo2.x, lo2.y, hi2.x, hi2.y);
-            if (f.x) stc(loc, flags + o + r0 + 4 * w, 0);
-            if (f.y) stc(loc, flags + o + r0 + 4 * w + 1, 0);
-            if (f.z) stc(loc, flags + o + r0 + 4 * w + 2, 0);
-            if (f.w) stc(loc, flags + o + r0 + 4 * w + 3, 0);
+            if (f.x | f.y) stc2(loc, flags + o + r0 + 4 * w, 0, 0);
+            if (f.z | f.w) stc2(loc, flags + o + r0 + 4 * w + 2, 0, 0);
           }
           const int cnt = (f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0);
           int incl = cnt;
@@ -1125,10 +1202,10 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
           }
           if (cnt > 0) {
             const int r = r0 + 4 * w;
-            if (f.x) stc(loc, &llist[pos++], a.ws.perm1[o + r]);
-            if (f.y) stc(loc, &llist[pos++], a.ws.perm1[o + r + 1]);
-            if (f.z) stc(loc, &llist[pos++], a.ws.perm1[o + r + 2]);
-            if (f.w) stc(loc, &llist[pos++], a.ws.perm1[o + r + 3]);
+            if (f.x) { stc2(loc, &llist[2 * pos], perm1[r], r); ++pos; }
+            if (f.y) { stc2(loc, &llist[2 * pos], perm1[r + 1], r + 1); ++pos; }
+            if (f.z) { stc2(loc, &llist[2 * pos], perm1[r + 2], r + 2); ++pos; }
+            if (f.w) { stc2(loc, &llist[2 * pos], perm1[r + 3], r + 3); ++pos; }
           }
           base += total;
           __syncthreads();
@@ -1160,74 +1237,118 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
       }
       if (a.diag) __syncthreads();
       tick(6);
-      if (!team_barrier(ts, &s_flag)) return;
-      tick(7);
-      // ---- GetMax (emd_cuda.cu:181-194) for the own bidders
-      // a thread serves the same list slots in GetMax and in Assign: what it looked up for its FIRST slot (the
-      // only one once a workgroup has <= 1024 bidders) stays in registers across the barrier -- two dependent
-      // round trips less at the head of Assign
-      int keep_j = -1, keep_tgt = -1;
-      float keep_inc = 0.f;
-      for (int u = tid; u < Um; u += kBidThreads) {
-        const int j = ldc(&llist[u]);
-        const int tgt = ldc(&bo.bid[o + j]);
-        const float bi = tgt < 0 ? 0.f : ldc(&bo.bid_inc[o + j]);
-        if (u == tid) {
-          keep_j = j;
-          keep_tgt = tgt;
-          keep_inc = bi;
-        }
-        if (tgt < 0) continue;
-        const float mi = ldc(&bo.max_inc[o + tgt]);
-        if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6)
-          __hip_atomic_fetch_max(&bo.win[o + tgt], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!team_barrier(ts, &s_flag)) {
+        bail(b);
+        return;
       }
-      if (a.diag) __syncthreads();
-      tick(8);
-      if (!team_barrier(ts, &s_flag)) return;
-      tick(9);
-      // ---- Assign (emd_cuda.cu:196-215) for the own bidders; raised flags are counted for the next U
+      tick(7);
+      // ---- award: GetMax (emd_cuda.cu:181-194) and Assign (:196-215) in one target-centric pass.
+      // Every bidder linked itself into its target's list during the bid phase; the bidder that is still the
+      // list's head after the barrier walks it.  With mi = the target's max_increments (the atomic maximum of
+      // this iteration's increments and whatever an earlier iteration left there, exactly the reference's
+      // tensor), the bidders inside the window |inc - mi| <= 1e-6 (double compare, :188) compete, the HIGHEST
+      // bidder index wins (the sequential order of :188-191); with nobody inside the window -- only possible
+      // for eps < 0, when every increment is below the tensor's initial 0 -- the persistent max_idx entry of an
+      // earlier iteration decides, as in the reference, which never clears that tensor (:181-194,
+      // emd_module.py:50).  The winner gets the target (eviction, price update, :203-211), every other bidder
+      // of the list is flagged to bid again.  In the last iteration every bidder takes its target (:200).
+      // One walker per target: no word is written by two threads, and what a walker reads was written before
+      // the barrier (lists, increments) or belongs to its target alone.
       {
         unsigned *nextbins = reinterpret_cast<unsigned *>(a.ws.bins[cur ^ 1] + b * kRankBins);
-        auto raise = [&](int rank) {  // counted per bin in LDS first: <= 64 device atomics per workgroup
+        auto raise = [&](int rank) {  // counted per bin in LDS first: <= 256 device atomics per workgroup
           stc(loc, &flags[o + rank], 1);
           atomicAdd(&s_bins[rank / binsize], 1);
         };
+        const int *rec = a.ws.rec + 2 * o;
         for (int u = tid; u < Um; u += kBidThreads) {
-          const bool kept = u == tid;
-          const int j = kept ? keep_j : ldc(&llist[u]);
-          const int tgt = kept ? keep_tgt : ldc(&bo.bid[o + j]);
+          int tgt, rank, inc_bits, nxt;
+          if (u < kStash) {
+            const BidStash sb = stash[u];
+            tgt = sb.tgt;
+            rank = sb.rank;
+            inc_bits = sb.inc_bits;
+            nxt = sb.next;
+          } else {
+            const int2 jr = ldc2(&llist[2 * u]);
+            tgt = ldc(&bo.bid[o + jr.x]);
+            rank = jr.y;
+            const int2 r2 = ldc2(&rec[2 * rank]);
+            inc_bits = r2.x;
+            nxt = r2.y;
+          }
           if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
-            if (!last) raise(a.ws.rank1[o + j]);
+            if (!last) raise(rank);
             continue;
           }
-          // GetMax only writes max_idx when some bidder's increment is within 1e-6 of max_increments, and the
-          // reference never clears that tensor (emd_cuda.cu:181-194, emd_module.py:50: zeros): when nobody is
-          // in the window -- max_increments still holds its initial 0 and every increment is negative, i.e.
-          // eps < 0 -- Assign compares against the entry of an EARLIER iteration (initially 0).  Every bidder
-          // of a target sees the same `win`, so they all take the same branch: no read races a write.
-          int w = ldc(&bo.win[o + tgt]);
-          if (w >= 0)
-            stc(loc, &a.ws.max_idx[o + tgt], w);
-          else
-            w = ldc(&a.ws.max_idx[o + tgt]);
-          if (last || w == j) {
-            const int inv = ldc(&a.ws.assignment_inv[o + tgt]);
-            if (!last && inv != -1) {
-              stc(loc, &a.assignment[o + inv], -1);
-              raise(a.ws.rank1[o + inv]);  // evicted: bids again
+          if (ldc(&bo.head[o + tgt]) != rank) continue;  // somebody else walks this target's list
+          // the four words of the target, requested together
+          const float mi = ldc(&bo.max_inc[o + tgt]);
+          const int wp = ldc(&a.ws.max_idx[o + tgt]);
+          const int inv = ldc(&a.ws.assignment_inv[o + tgt]);
+          const float pr = ldc(&price[o + tgt]);
+          int w_rank = -1, w_j = -1, p_inc = 0;
+          float w_inc = 0.f;
+          bool persist_hit = false;
+          for (int cr = rank, ci = inc_bits, cn = nxt;;) {
+            const float bi = __int_as_float(ci);
+            if (last) {  // forced assignment (:200): every bidder takes its target; prices still accumulate (:209)
+              stc(loc, &a.assignment[o + perm1[cr]], tgt);
+              w_inc += bi;  // several claimants: a race in the reference, list order here
+            } else if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6) {
+              if (w_rank < 0) {
+                w_rank = cr;
+                w_inc = bi;
+              } else {  // several bidders inside the window: the highest bidder INDEX wins
+                if (w_j < 0) w_j = perm1[w_rank];
+                const int jc = perm1[cr];
+                if (jc > w_j) {
+                  raise(w_rank);
+                  w_rank = cr;
+                  w_j = jc;
+                  w_inc = bi;
+                } else {
+                  raise(cr);
+                }
+              }
+            } else if (cr == wp) {  // outside the window, but the persistent winner: decided after the walk
+              persist_hit = true;
+              p_inc = ci;
+            } else {
+              raise(cr);
             }
-            stc(loc, &a.ws.assignment_inv[o + tgt], j);
-            stc(loc, &a.assignment[o + j], tgt);
-            const float np = ldc(&price[o + tgt]) + (kept ? keep_inc : ldc(&bo.bid_inc[o + j]));
-            stc(loc, &price[o + tgt], np);
-            const int pos = a.ws.rank2[o + tgt];  // the bid phase reads the price by stream position
-            stc(loc, reinterpret_cast<float *>(a.ws.pk + o + pos), np);
-            stc(loc, a.ws.prt + o + ((pos >> 6) * 64 + (pos & 15) * 4 + ((pos >> 4) & 3)), np);  // [sb][c][q]
-            stc(loc, &bo.max_inc[o + tgt], -1e9f);
-          } else {
-            raise(a.ws.rank1[o + j]);  // lost: bids again
+            if (cn < 0) break;
+            const int2 r2 = ldc2(&rec[2 * cn]);
+            cr = cn;
+            ci = r2.x;
+            cn = r2.y;
           }
+          stc(loc, &bo.head[o + tgt], -1);
+          if (last) {
+            stc(loc, &price[o + tgt], pr + w_inc);
+            continue;
+          }
+          if (w_rank >= 0) {
+            stc(loc, &a.ws.max_idx[o + tgt], w_rank);
+            if (persist_hit) raise(wp);
+          } else if (persist_hit) {
+            w_rank = wp;
+            w_inc = __int_as_float(p_inc);
+          }
+          if (w_rank < 0) continue;  // nobody wins this target in this iteration
+          if (w_j < 0) w_j = perm1[w_rank];
+          if (inv != -1) {
+            stc(loc, &a.assignment[o + inv], -1);
+            raise(a.ws.rank1[o + inv]);  // evicted: bids again
+          }
+          stc(loc, &a.ws.assignment_inv[o + tgt], w_j);
+          stc(loc, &a.assignment[o + w_j], tgt);
+          const float np = pr + w_inc;
+          stc(loc, &price[o + tgt], np);
+          const int pos = a.ws.rank2[o + tgt];  // the bid phase reads the price by stream position
+          stc(loc, reinterpret_cast<float *>(a.ws.pk + o + pos), np);
+          stc(loc, a.ws.prt + o + ((pos >> 6) * 64 + (pos & 15) * 4 + ((pos >> 4) & 3)), np);  // [sb][c][q]
+          stc(loc, &bo.max_inc[o + tgt], -1e9f);
         }
         __syncthreads();
         if (tid < kRankBins) {
@@ -1239,9 +1360,12 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
         }
       }
       if (a.diag) __syncthreads();
-      tick(10);
-      if (!team_barrier(ts, &s_flag)) return;
-      tick(11);
+      tick(8);
+      if (!team_barrier(ts, &s_flag)) {
+        bail(b);
+        return;
+      }
+      tick(9);
     }
     // ---- distances of the final assignment (emd_cuda.cu:218-226), own slice of the bidder indices
     {
@@ -1289,21 +1413,22 @@ constexpr size_t kCtlBytes = 4 * kCtlWords + 8 * kDiagWords;
 EmdWs carve(void *workspace, int b, int n) {
   char *p = static_cast<char *>(workspace);
   const size_t arr = sn::align_up((size_t)b * n * 4, 256);
+  const size_t arr2 = sn::align_up((size_t)b * n * 8, 256);
   EmdWs ws;
   ws.assignment_inv = reinterpret_cast<int *>(p); p += arr;
   ws.price = reinterpret_cast<float *>(p); p += arr;
   ws.bid = reinterpret_cast<int *>(p); p += arr;
   ws.bid2 = reinterpret_cast<int *>(p); p += arr;
-  ws.bid_inc = reinterpret_cast<float *>(p); p += arr;
+  ws.rec = reinterpret_cast<int *>(p); p += arr2;
   ws.max_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_idx = reinterpret_cast<int *>(p); p += arr;
-  ws.win = reinterpret_cast<int *>(p); p += arr;
-  ws.list[0] = reinterpret_cast<int *>(p); p += arr;
+  ws.head = reinterpret_cast<int *>(p); p += arr;
+  ws.list[0] = reinterpret_cast<int *>(p); p += arr2;
   ws.prt = reinterpret_cast<float *>(p); p += arr;
   ws.bins[0] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
   ws.bins[1] = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * kRankBins * 4, 256);
   ws.t4s = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
-  ws.pk = reinterpret_cast<float2 *>(p); p += sn::align_up((size_t)b * n * 8, 256);
+  ws.pk = reinterpret_cast<float2 *>(p); p += arr2;
   ws.rank2 = reinterpret_cast<int *>(p); p += arr;
   ws.mstream = reinterpret_cast<f4 *>(p); p += sn::align_up((size_t)b * n * 16, 256);
   ws.tperm = reinterpret_cast<int *>(p); p += arr;
@@ -1320,19 +1445,182 @@ EmdWs carve(void *workspace, int b, int n) {
   return ws;
 }
 
+// ---- once per device: does this GPU behave the way the fence-free barriers and the XCD-local plain stores assume?
+// The persistent auction hands data between workgroups with relaxed accesses only (see team_barrier, stc).  That is
+// gfx950 cache behaviour, not a promise of the HIP memory model, and the XCD of a workgroup is read from a raw
+// hardware register.  emd_litmus_kernel replays both hand-overs on every workgroup of a full grid for `rounds`
+// rounds: each workgroup publishes a word per round (a) with an agent-scope (sc1) store and (b) with a plain
+// (workgroup-scope) store, all workgroups meet at a fence-free barrier, then every workgroup reads every other
+// workgroup's (a) word -- and the (b) word of those that reported the same XCC id -- with coherent loads and
+// counts stale values.  res[0] = stale agent-scope words, res[1] = stale same-XCD plain words, res[2] = barrier
+// time-outs, res[3] = workgroups that ran, res[4 + x] = workgroups that reported XCC id x.
+__global__ __launch_bounds__(64) void emd_litmus_kernel(unsigned *ctl, unsigned *xcc_of, unsigned *agent_words,
+                                                        unsigned *plain_words, unsigned *res, int W, int rounds) {
+  __shared__ int s_me, s_ok;
+  const int lane = threadIdx.x;
+  if (lane == 0) {
+    s_me = (int)__hip_atomic_fetch_add(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_ok = 1;
+  }
+  __syncthreads();
+  const int me = s_me;
+  if (me >= W) return;
+  const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u;
+  if (lane == 0) {
+    __hip_atomic_store(&xcc_of[me], xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(&res[3], 1u);
+    atomicAdd(&res[4 + xcc], 1u);
+  }
+  unsigned target = 0;
+  auto barrier = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    target += (unsigned)W;
+    if (lane == 0) {
+      __hip_atomic_fetch_add(&ctl[32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(&ctl[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 21) || __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          __hip_atomic_store(&ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_ok = 0;
+          break;
+        }
+      }
+    }
+    __syncthreads();
+    return s_ok != 0;
+  };
+  if (!barrier()) {
+    if (lane == 0) atomicAdd(&res[2], 1u);
+    return;
+  }
+  unsigned bad_agent = 0, bad_plain = 0;
+  for (int r = 1; r <= rounds; ++r) {
+    if (lane == 0) {
+      // a different line every round (a line that is already shared would hide a missing write-through)
+      __hip_atomic_store(&agent_words[(size_t)(r & 7) * W * 16 + (size_t)me * 16], (unsigned)(r * 65536 + me),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&plain_words[(size_t)(r & 7) * W * 16 + (size_t)me * 16], (unsigned)(r * 65536 + me),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (!barrier()) {
+      if (lane == 0) atomicAdd(&res[2], 1u);
+      return;
+    }
+    for (int v = lane; v < W; v += 64) {
+      const unsigned want = (unsigned)(r * 65536 + v);
+      const unsigned ga = __hip_atomic_load(&agent_words[(size_t)(r & 7) * W * 16 + (size_t)v * 16], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
+      bad_agent += ga != want;
+      if (__hip_atomic_load(&xcc_of[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == xcc) {
+        const unsigned gp = __hip_atomic_load(&plain_words[(size_t)(r & 7) * W * 16 + (size_t)v * 16],
+                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad_plain += gp != want;
+      }
+    }
+    if (!barrier()) {  // nobody overwrites a slot (8 rounds later) before everybody has read it
+      if (lane == 0) atomicAdd(&res[2], 1u);
+      return;
+    }
+  }
+  if (bad_agent) atomicAdd(&res[0], bad_agent);
+  if (bad_plain) atomicAdd(&res[1], bad_plain);
+}
+
+struct DeviceState {
+  int verified = 0;       // 0: not yet, 1: fence-free + XCD-local paths verified, 2: fall back (fenced, agent-scope stores)
+  int tries = 0;
+  unsigned *sticky = nullptr;   // pinned host word, device-visible: a barrier of some launch gave up
+  unsigned *sticky_dev = nullptr;  // the same word as the device addresses it
+  char why[160] = {0};
+};
+std::mutex g_dev_mu;
+DeviceState g_dev[64];
+
+// runs the litmus on `dev` (synchronises the device once); fills st.verified / st.why
+void verify_device(DeviceState &st, int dev, int cus) {
+  st.tries++;
+  const int W = cus, rounds = 24;
+  const size_t words = 64 + (size_t)W + 2 * 8 * (size_t)W * 16 + 16;
+  unsigned *buf = nullptr;
+  if (hipMalloc(reinterpret_cast<void **>(&buf), words * 4) != hipSuccess) {
+    st.verified = 2;
+    snprintf(st.why, sizeof st.why, "self-test: hipMalloc failed");
+    return;
+  }
+  (void)hipMemset(buf, 0, words * 4);
+  unsigned *ctl = buf, *xcc_of = buf + 64, *aw = xcc_of + W, *pw = aw + 8 * (size_t)W * 16, *res = pw + 8 * (size_t)W * 16;
+  emd_litmus_kernel<<<W, 64, 0, 0>>>(ctl, xcc_of, aw, pw, res, W, rounds);
+  unsigned r[16] = {0};
+  const hipError_t e = hipMemcpy(r, res, sizeof r, hipMemcpyDeviceToHost);
+  (void)hipFree(buf);
+  if (e != hipSuccess) {
+    st.verified = 2;
+    snprintf(st.why, sizeof st.why, "self-test: %s", hipGetErrorString(e));
+    return;
+  }
+  if (r[2] != 0 || (int)r[3] != W) {  // the grid was not co-resident (busy device): undecided, try again later
+    if (st.tries >= 3) {
+      st.verified = 2;
+      snprintf(st.why, sizeof st.why, "self-test could not run on an idle device (3 tries)");
+    }
+    return;
+  }
+  if (r[0] != 0 || r[1] != 0) {
+    st.verified = 2;
+    snprintf(st.why, sizeof st.why, "self-test: %u stale agent-scope words, %u stale same-XCD plain words", r[0], r[1]);
+    return;
+  }
+  st.verified = 1;
+}
+
 }  // namespace
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 16 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * kRankBins * 4, 256) +
-         2 * sn::align_up((size_t)b * n * 16, 256) + sn::align_up((size_t)b * n * 8, 256) + 2 * (size_t)b * kSortCells * 4 +
-         2 * sn::align_up((size_t)b * 24, 256) + sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
+  return 15 * sn::align_up((size_t)b * n * 4, 256) + 3 * sn::align_up((size_t)b * n * 8, 256) +
+         2 * sn::align_up((size_t)b * kRankBins * 4, 256) + 2 * sn::align_up((size_t)b * n * 16, 256) +
+         2 * (size_t)b * kSortCells * 4 + 2 * sn::align_up((size_t)b * 24, 256) +
+         sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
 }
 
 // byte offset of the diagnostic words (SN_EMD_DIAG) inside the workspace
 extern "C" size_t sn_emd_diag_offset(int b, int n) {
   return sn_emd_workspace_bytes(b, n) - 8 * kDiagWords;
 }
+
+// 0: the fence-free / XCD-local paths are in use on the current device; 2: the library fell back to fenced
+// barriers and agent-scope stores (SN_EMD_SAFE=1 or a failed self-test: sn_last_error() says why); -1: not decided
+// yet (no sn_emd_forward call on this device so far).
+extern "C" int sn_emd_mode(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  const char *e = getenv("SN_EMD_SAFE");
+  if (e && e[0] == '1') return 2;
+  if (g_dev[dev].verified == 2) {
+    sn::fail(0, "%s", g_dev[dev].why);
+    return 2;
+  }
+  return g_dev[dev].verified == 1 ? 0 : -1;
+}
+
+namespace {
+// the sticky word of a device: set by a launch whose barrier gave up, reported (and cleared) by the next call
+int check_sticky(int dev, const char *what) {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  unsigned *w = g_dev[dev].sticky;
+  if (w && *reinterpret_cast<volatile unsigned *>(w) != 0u) {
+    *reinterpret_cast<volatile unsigned *>(w) = 0u;
+    return sn::fail(SN_ETIMEDOUT,
+                    "%s: a team barrier of an EARLIER persistent auction launch on this device timed out (the device "
+                    "is shared, or a debugger holds a compute unit); that call's dist / assignment were filled with "
+                    "NaN / -1", what);
+  }
+  return 0;
+}
+}  // namespace
 
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
                               int iters, float *dist, int *assignment, void *workspace,
@@ -1346,6 +1634,42 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
              "sn_emd_forward: workspace too small (%zu < %zu)", workspace_bytes,
              sn_emd_workspace_bytes(b, n));
   hipStream_t s = sn::as_stream(stream);
+  int dev = 0, cus = 0;
+  SN_HIP(hipGetDevice(&dev));
+  SN_REQUIRE(dev >= 0 && dev < 64, "sn_emd_forward: unexpected device ordinal %d", dev);
+  if (const int rc = check_sticky(dev, "sn_emd_forward")) return rc;
+  SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  SN_REQUIRE(cus >= 1 && cus <= 1024, "sn_emd_forward: unexpected compute-unit count %d", cus);
+  const char *safe_env = getenv("SN_EMD_SAFE");   // read per call: tests switch it inside one process
+  int safe = safe_env && safe_env[0] == '1';
+  unsigned *sticky = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    DeviceState &st = g_dev[dev];
+    if (!st.sticky) {
+      void *h = nullptr;
+      if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+        *static_cast<unsigned *>(h) = 0u;
+        void *d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+          st.sticky = static_cast<unsigned *>(h);
+          st.sticky_dev = static_cast<unsigned *>(d);
+        }
+      }
+      (void)hipGetLastError();
+    }
+    sticky = st.sticky_dev;
+    if (!safe && st.verified == 0) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      (void)hipStreamIsCapturing(s, &cap);
+      if (cap == hipStreamCaptureStatusNone) {
+        verify_device(st, dev, cus);
+        if (st.verified == 2) fprintf(stderr, "sparenet_hip: EMD falls back to fenced barriers on device %d: %s\n", dev, st.why);
+      }
+      (void)hipGetLastError();
+    }
+    if (st.verified != 1) safe = 1;   // unverified (yet) or failed: the conservative path
+  }
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
@@ -1358,10 +1682,6 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
   emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
   {
-    int dev = 0, cus = 0;
-    SN_HIP(hipGetDevice(&dev));
-    SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    SN_REQUIRE(cus >= 1 && cus <= 1024, "sn_emd_forward: unexpected compute-unit count %d", cus);
     // one workgroup of 16 waves per CU (the register budget admits exactly one): the whole grid is resident
     // on an idle device, and the ticket order keeps it live next to other launches (see the kernel's header)
     AuctionArgs args;
@@ -1375,18 +1695,28 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     args.dist = dist;
     args.ws = ws;
     args.ctl = static_cast<AuctionCtl *>(ws.ctl);
+    args.sticky = sticky;
+    args.safe = safe;
     args.stats = stats;
-    args.tg = team_geometry(b, cus);
     static const int diag = [] { const char *e = getenv("SN_EMD_DIAG"); return e ? atoi(e) : 0; }();
+    static const int gmax = [] { const char *e = getenv("SN_EMD_G"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
+    static const int legacy = [] { const char *e = getenv("SN_EMD_GEOM"); return e && e[0] == '1' ? 1 : 0; }();
+    args.tg = team_geometry(b, cus, gmax, legacy);
     args.diag = diag;
+    args.spin_limit = (diag & 8) ? (1u << 15) : kSpinLimit;
     args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
+    SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
     SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus, kBidThreads, 0, s>>>(args)));
-    if (check) {  // debugging aid: a barrier that timed out leaves garbage in dist / assignment
+    if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;
       SN_HIP(hipStreamSynchronize(s));
       SN_HIP(hipMemcpy(&abort_word, &args.ctl->abort, 4, hipMemcpyDeviceToHost));
+      if (abort_word != 0) {
+        std::lock_guard<std::mutex> lk(g_dev_mu);
+        if (g_dev[dev].sticky) *reinterpret_cast<volatile unsigned *>(g_dev[dev].sticky) = 0u;
+      }
       SN_REQUIRE(abort_word == 0, "sn_emd_forward: a team barrier of the persistent auction timed out");
     }
     return sn::launch_status("sn_emd_forward");
@@ -1398,6 +1728,12 @@ extern "C" int sn_emd_backward(const float *xyz1, const float *xyz2, const float
                                void *stream) {
   SN_REQUIRE(xyz1 && xyz2 && graddist && assignment && gradxyz1, "sn_emd_backward: null pointer");
   SN_REQUIRE(b >= 1 && n >= 1, "sn_emd_backward: need b,n >= 1");
+  {
+    int dev = 0;
+    SN_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64)
+      if (const int rc = check_sticky(dev, "sn_emd_backward")) return rc;
+  }
   const long total = (long)b * n;
   const int blocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
   emd_bwd_kernel<<<blocks, kThreads, 0, sn::as_stream(stream)>>>(b, n, xyz1, xyz2, graddist,

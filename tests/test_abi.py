@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 28
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sparenet_hip.h but not exported"
-    assert lib.sn_abi_version() == 1
+    assert lib.sn_abi_version() == 3
 
 
 def test_argument_validation_without_gpu():
@@ -43,10 +43,11 @@ def test_argument_validation_without_gpu():
                                     ctypes.c_size_t(1 << 20), null) == -22
     assert b"power of two" in lib.sn_last_error()
     assert lib.sn_mds(one, 1, 10, 20, one, one, null, ctypes.c_size_t(0), null) == -22
-    lib.sn_emd_workspace_bytes.restype = ctypes.c_size_t
     ctl = 4 * (32 + 32 * 1024) + 8 * (16 + 64 * 64)   # persistent auction: barrier counters + diag words
-    assert lib.sn_emd_workspace_bytes(32, 16384) == (16 * 32 * 16384 * 4 + 2 * 32 * 256 * 4 + 2 * 32 * 16384 * 16 + 32 * 16384 * 8
-                                                      + 2 * 32 * 4096 * 4 + 2 * 768 + 32 * 1024 * 32 + ctl)
+    # 15 word arrays + 3 arrays of 8-byte entries (bid records, {index, rank} lists, {price, index} stream) + ...
+    assert lib.sn_emd_workspace_bytes(32, 16384) == (15 * 32 * 16384 * 4 + 3 * 32 * 16384 * 8 + 2 * 32 * 256 * 4
+                                                      + 2 * 32 * 16384 * 16 + 2 * 32 * 4096 * 4 + 2 * 768
+                                                      + 32 * 1024 * 32 + ctl)
 
 
 def test_no_cpu_fallback_anywhere():

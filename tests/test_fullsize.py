@@ -14,6 +14,9 @@ dense scan loop of the sampler), so the headline configuration itself is pinned 
   * Chamfer + expansion on whole C2 clouds.
 The oracle is OpenMP C; every case finishes in seconds.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -94,12 +97,14 @@ def test_emd_whole_benched_batch_bit_exact(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("b,n,iters", [(33, 2048, 30), (70, 1024, 25), (300, 1024, 8), (7, 4096, 12), (16, 2048, 20)])
+@pytest.mark.parametrize("b,n,iters", [(33, 2048, 30), (70, 1024, 25), (300, 1024, 8), (7, 4096, 12), (16, 2048, 20),
+                                       (1, 4096, 14), (2, 2048, 25), (4, 16384, 12), (8, 2048, 30), (12, 1024, 50)])
 def test_emd_team_geometries(b, n, iters, dev):
     """Batch sizes that change the persistent auction's team geometry: 33 / 70 clouds (teams of 4 / 2
-    workgroups per cloud), 300 (teams of one workgroup serving several clouds in turn), 7 and 16 (contiguous
-    teams of 32 / 16 workgroups spanning XCDs).  Every word the workgroups exchange goes through coherent
-    accesses without fences: any stale read shows up here as a diverging assignment."""
+    workgroups per cloud), 300 (teams of one workgroup serving several clouds in turn); 1 ... 8 clouds (one team
+    of 32 workgroups = a whole XCD per cloud: the strong-scaling shares of a 2 / 4 / 8-GPU job), 12 and 16 (two
+    teams of 16 per XCD).  Every word the workgroups exchange goes through coherent accesses without fences:
+    any stale read shows up here as a diverging assignment."""
     g = torch.Generator().manual_seed(b * 7 + n)
     x = torch.rand(b, n, 3, generator=g).numpy()
     y = torch.rand(b, n, 3, generator=g).numpy()
@@ -295,7 +300,6 @@ dev = torch.device("cuda:0")
 d, a, ws = emd_forward_raw(x.to(dev), y.to(dev), 0.005, 12, return_workspace=True)
 torch.cuda.synchronize()
 import ctypes
-L.lib().sn_emd_diag_offset.restype = ctypes.c_size_t
 off = L.lib().sn_emd_diag_offset(b, n)
 local_teams = int(ws[off:off + 8 * 16].view(torch.int64)[12])
 print("RESULT", int(np.array_equal(a.cpu().numpy(), a0)), int(np.array_equal(d.cpu().numpy(), d0)), local_teams)
@@ -308,3 +312,69 @@ print("RESULT", int(np.array_equal(a.cpu().numpy(), a0)), int(np.array_equal(d.c
         same_a, same_d, local_teams = (int(v) for v in line[0].split()[1:])
         assert same_a == 1 and same_d == 1, (diag, line)
         assert local_teams == want_local, (diag, local_teams)
+
+
+_SUBPROCESS_HEAD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import oracle
+import sparenet_amd._lib as L
+from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
+dev = torch.device("cuda:0")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_emd_barrier_timeout_is_loud_without_a_sync():
+    """A team member that never arrives (SN_EMD_DIAG=8 parks one workgroup and shortens the spin limit): every
+    workgroup leaves, the unfinished clouds come back as NaN / -1 -- never as plausible numbers -- and the NEXT
+    sn_emd_* call on the device fails with SN_ETIMEDOUT, with SN_EMD_CHECK unset (no host synchronisation in the
+    failing call).  The reference returns an error code from emd_cuda_forward (emd_cuda.cu:276-281)."""
+    import subprocess
+    code = _SUBPROCESS_HEAD + r"""
+g = torch.Generator().manual_seed(1)
+x, y = torch.rand(2, 1024, 3, generator=g).to(dev), torch.rand(2, 1024, 3, generator=g).to(dev)
+d, a = emd_forward_raw(x, y, 0.005, 10)          # returns normally: nothing is synchronised
+torch.cuda.synchronize()
+nan0 = bool(torch.isnan(d[0]).all()) and bool((a[0] == -1).all())
+clean1 = bool(torch.isnan(d[1]).all() and (a[1] == -1).all()) or bool(torch.isfinite(d[1]).all() and (a[1] >= 0).all())
+try:
+    emd_forward_raw(x, y, 0.005, 10)
+    raised = 0
+except L.SparenetHipError as e:
+    raised = int("timed out" in str(e) and "-110" in str(e))
+print("RESULT", int(nan0), int(clean1), raised)
+"""
+    env = {k: v for k, v in os.environ.items() if k != "SN_EMD_CHECK"}
+    env["SN_EMD_DIAG"] = "8"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stderr[-2000:]
+    assert line[0].split()[1:] == ["1", "1", "1"], (line, out.stderr[-1000:])
+
+
+@pytest.mark.gpu
+def test_emd_self_test_passes_and_safe_mode_is_bit_exact(dev):
+    """The once-per-device litmus behind the fence-free barriers and the XCD-local plain stores passes on an
+    MI355X (sn_emd_mode() == 0 after the first call), and the conservative path it would fall back to -- agent-scope
+    release / acquire barriers, agent-scope stores, SN_EMD_SAFE=1 (read per call) -- gives the same bits."""
+    import sparenet_amd._lib as L
+
+    x, y = _clouds(3, "uniform", 21)
+    d0, a0, aux = oracle.emd_forward(x, y, 0.005, 12, mt=True, return_aux=True)
+    (d, a), st = _emd_raw(x, y, 0.005, 12, dev)
+    assert np.array_equal(a.cpu().numpy(), a0) and np.array_equal(d.cpu().numpy(), d0)
+    assert L.lib().sn_emd_mode() == 0, L.lib().sn_last_error()
+    os.environ["SN_EMD_SAFE"] = "1"
+    try:
+        assert L.lib().sn_emd_mode() == 2
+        (d, a), st = _emd_raw(x, y, 0.005, 12, dev)
+        assert np.array_equal(a.cpu().numpy(), a0) and np.array_equal(d.cpu().numpy(), d0)
+        assert int(st[0]) == aux["pairs_eff"]
+        g = torch.Generator().manual_seed(5)
+        xb, yb = torch.rand(32, 2048, 3, generator=g).numpy(), torch.rand(32, 2048, 3, generator=g).numpy()
+        db, ab = oracle.emd_forward(xb, yb, 0.005, 20, mt=True)
+        (d, a), _ = _emd_raw(xb, yb, 0.005, 20, dev)
+        assert np.array_equal(a.cpu().numpy(), ab) and np.array_equal(d.cpu().numpy(), db)
+    finally:
+        del os.environ["SN_EMD_SAFE"]

@@ -30,9 +30,10 @@ if "--parity32" in sys.argv:   # the benched batch (XCD-local teams), 50 iterati
         d, a = emd_forward_raw(X.to(dev), Y.to(dev), 0.005, 50, st)
         print(mode, "parity b 32 iters 50 run", rep, bool(np.array_equal(a.cpu().numpy(), a0)),
               bool(np.array_equal(d.cpu().numpy(), d0)), int(st[0]) == aux["pairs_eff"], flush=True)
-for b in ((32,) if os.environ.get("AB_QUICK") else (32, 4, 1)):
+_BS = tuple(int(v) for v in os.environ["AB_BS"].split(",")) if os.environ.get("AB_BS") else None
+for b in (_BS or ((32,) if os.environ.get("AB_QUICK") else (32, 4, 1))):
     x, y = X[:b].to(dev), Y[:b].to(dev)
-    for iters in ((50,) if os.environ.get("AB_QUICK") else (1, 10, 50)):
+    for iters in ((50,) if (os.environ.get("AB_QUICK") or _BS) else (1, 10, 50)):
         emd_forward_raw(x, y, 0.005, iters); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -45,10 +46,9 @@ if os.environ.get("SN_EMD_DIAG"):
     for b in (int(os.environ.get("AB_DIAG_B", "32")),):   # AB_DIAG_B=4: the strong-scaling share of an 8-GPU job
         x, y = X[:b].to(dev), Y[:b].to(dev)
         _, _, ws = emd_forward_raw(x, y, 0.005, 50, return_workspace=True); torch.cuda.synchronize()
-        _L.lib().sn_emd_diag_offset.restype = __import__("ctypes").c_size_t
         off = _L.lib().sn_emd_diag_offset(b, N)
         v = ws[off:off + 8 * (16 + 64 * 64)].view(torch.int64).cpu().numpy()
-        names = ["compact", "-", "bid", "bar1", "getmax", "bar2", "assign", "bar3"]
+        names = ["compact", "-", "bid", "bar1", "award", "bar2", "-", "-"]
         print("teams with every workgroup on one XCD (plain stores):", int(v[12]))
         print("team 0 / wg 0 phase time, us over the call:", {n_: round(float(v[4 + i]) / 100.0, 1) for i, n_ in enumerate(names)})
         if os.environ.get("SN_EMD_DIAG") == "2":
