@@ -204,9 +204,13 @@ class HotPath:
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream()
+        # tensors that cross streams are registered with the caching allocator: a block freed on its own stream
+        # could otherwise be handed out again while the other stream still reads it
+        pred.record_stream(self.side)
         self.side.wait_stream(main)
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
+        acc.record_stream(main)
         loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt)
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])

@@ -390,9 +390,13 @@ struct BidOut {
   bool loc;  // the team sits on one XCD: plain stores (see stc)
 };
 
-constexpr int kBidWaves = 16;
+#ifndef SN_EMD_BIDWAVES
+#define SN_EMD_BIDWAVES 16   // waves per workgroup; 16 / SN_EMD_BIDWAVES workgroups share a CU
+#endif
+constexpr int kBidWaves = SN_EMD_BIDWAVES;
 constexpr int kBidThreads = kBidWaves * 64;
-constexpr int kStash = 1024;  // list slots whose bid is handed to the award phase through LDS
+constexpr int kWgPerCu = 16 / kBidWaves;
+constexpr int kStash = kBidThreads;  // list slots whose bid is handed to the award phase through LDS
 
 // What the award phase needs to know about the bid of list slot u (written by the wave that emits the bid, read
 // after the team barrier by thread u): saves the llist -> bid -> rec chain of dependent coherent loads.
@@ -1579,7 +1583,7 @@ void verify_device(DeviceState &st, int dev, int cus) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 15 * sn::align_up((size_t)b * n * 4, 256) + 3 * sn::align_up((size_t)b * n * 8, 256) +
+  return 14 * sn::align_up((size_t)b * n * 4, 256) + 3 * sn::align_up((size_t)b * n * 8, 256) +
          2 * sn::align_up((size_t)b * kRankBins * 4, 256) + 2 * sn::align_up((size_t)b * n * 16, 256) +
          2 * (size_t)b * kSortCells * 4 + 2 * sn::align_up((size_t)b * 24, 256) +
          sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
@@ -1701,14 +1705,14 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     static const int diag = [] { const char *e = getenv("SN_EMD_DIAG"); return e ? atoi(e) : 0; }();
     static const int gmax = [] { const char *e = getenv("SN_EMD_G"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
     static const int legacy = [] { const char *e = getenv("SN_EMD_GEOM"); return e && e[0] == '1' ? 1 : 0; }();
-    args.tg = team_geometry(b, cus, gmax, legacy);
+    args.tg = team_geometry(b, cus * kWgPerCu, gmax, legacy);
     args.diag = diag;
     args.spin_limit = (diag & 8) ? (1u << 15) : kSpinLimit;
     args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
-    SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus, kBidThreads, 0, s>>>(args)));
+    SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, 0, s>>>(args)));
     if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;
       SN_HIP(hipStreamSynchronize(s));

@@ -167,8 +167,9 @@ def test_p2i_multi_radius_bench_configuration(dev):
         for r, R in enumerate(radii):
             o, i = oracle.p2i_max_forward(pn, fn, bn, bg.cpu().numpy(), R)
             np.testing.assert_allclose(out[r].cpu().numpy(), o, rtol=2e-6, atol=1e-7)
-            bad = ids[r].cpu().numpy() != i
-            assert bad.mean() < 1e-4, (v, R, int(bad.sum()))
+            from p2i_check import assert_ids_exact_up_to_ulp_ties
+            ties = assert_ids_exact_up_to_ulp_ties(ids[r].cpu().numpy(), i, pn, fn, 0.0, R, f"view {v} R={R}")
+            assert ties <= B * S * S // 10000, (v, R, ties)     # exact everywhere else
 
 
 @pytest.mark.gpu

@@ -34,7 +34,17 @@ def test_fused_metrics_match_definitions(dev):
     gt = rng.random((2, 2048, 3), dtype=np.float32) - 0.5
     pred = (gt[:, rng.permutation(2048)] + 0.004 * rng.standard_normal((2, 2048, 3))).astype(np.float32)
     m = fused_validation_metrics(torch.from_numpy(pred).to(dev), torch.from_numpy(gt).to(dev), th=0.01)
+    import oracle
+    o1, o2, _, _ = oracle.chamfer_forward(pred, gt)          # bit-equal to the HIP distances (tests/test_chamfer.py)
+    th2 = 0.01 * 0.01
     for b in range(2):
+        # exact: the threshold counts are integer work on distances that are bit-equal to the oracle's
+        p_cnt, r_cnt = int((o1[b] < th2).sum()), int((o2[b] < th2).sum())
+        prec, rec = p_cnt / o1.shape[1], r_cnt / o2.shape[1]
+        want = 2 * prec * rec / (prec + rec) if prec + rec else 0.0
+        assert abs(float(m["F-Score"][b]) - want) < 1e-12, (p_cnt, r_cnt)
+        # and an independent definition (exact k-d tree in double): counts may differ only for points whose
+        # distance is within rounding of the threshold
         assert abs(float(m["F-Score"][b]) - _f_score_ref(pred[b], gt[b], 0.01)) < 1e-3
         d1 = cKDTree(gt[b].astype(np.float64)).query(pred[b].astype(np.float64))[0] ** 2
         d2 = cKDTree(pred[b].astype(np.float64)).query(gt[b].astype(np.float64))[0] ** 2

@@ -24,4 +24,14 @@ for n in (1, 2, 4, 8):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 30 * 1e3
     base = base or ms
-    print(f"N = {n}: {b:2d} clouds per GPU: {ms:.2f} ms per step -> speed-up {base / ms:.2f} of {n} ({base / ms / n:.0%})")
+    timers = []
+    for _ in range(10):
+        hp.step(pred, gt, timers)
+    torch.cuda.synchronize()
+    seg = {}
+    for i in range(1, len(timers)):
+        name, ev = timers[i]
+        if name != "start":
+            seg[name] = seg.get(name, 0.0) + timers[i - 1][1].elapsed_time(ev) / 10
+    print(f"N = {n}: {b:2d} clouds per GPU: {ms:.2f} ms per step -> speed-up {base / ms:.2f} of {n} ({base / ms / n:.0%})"
+          f"   one stream: " + " ".join(f"{k} {v:.2f}" for k, v in seg.items()) + f" = {sum(seg.values()):.2f} ms")
