@@ -31,8 +31,11 @@ from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansi
 from sparenet_amd.cuda.MDS import MDS_module
 
 
+AUTOCAST = True   # bf16 autocast around the convolutions / linears on the GPU (tests switch it off to compare in fp32)
+
+
 def _autocast(t):
-    return torch.autocast(t.device.type, dtype=torch.bfloat16, enabled=t.is_cuda)
+    return torch.autocast(t.device.type, dtype=torch.bfloat16, enabled=t.is_cuda and AUTOCAST)
 
 
 def knn_indices(x, k):

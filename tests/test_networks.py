@@ -205,3 +205,115 @@ def test_gan_step_with_reference_networks(dev):
     assert all(torch.isfinite(out[k]).all() for k in ("rec_loss", "errG", "errG_D", "errD_real", "errD_fake"))
     assert any(not torch.equal(a, b) for a, b in zip(before_g, gen.parameters()))
     assert any(not torch.equal(a, b) for a, b in zip(before_d, disc.parameters()))
+
+
+# ------------------------------------------------------------------ GPU: the blocks against the reference classes
+def _block_case(name, z):
+    if name.startswith("networks_encoder"):
+        return (nw.EdgeConvEncoder(int(z["hide"]), int(z["out"]), int(z["bott"]), use_se=bool(z["use_se"])), "x")
+    if name == "networks_decoder":
+        P, n = int(z["P"]), int(z["n"])
+        return nw.StyleFoldingDecoder(P * n, P, int(z["style_dim"]), int(z["width"])), "style"
+    return nw.PointNetResidual(False), "x"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["networks_encoder", "networks_encoder_se", "networks_decoder", "networks_residual"])
+def test_blocks_on_the_gpu_match_reference_classes(name, golden_dir, dev):
+    """The same goldens as the CPU tests above (outputs of the REFERENCE's own classes), on the MI355X: with
+    autocast off this is the first numeric check of the HIP graph path -- sn_knn (fused fp32 MFMA search) ->
+    sn_graph_feature inside EdgeConvEncoder -- against the reference classes, at the CPU tolerance 2e-4; the bf16
+    autocast pass is then compared with the fp32 pass of the same module (see below)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    mod, key = _block_case(name, z)
+    mod = _load(mod, z).to(dev)
+    x = torch.from_numpy(z[key]).to(dev)
+    try:
+        nw.AUTOCAST = False
+        y32 = mod(x).detach().cpu().numpy()
+    finally:
+        nw.AUTOCAST = True
+    np.testing.assert_allclose(y32, z["y"], rtol=2e-4, atol=2e-5)
+    # bf16 autocast (how the step runs) against the fp32 pass of the SAME module, both in eval mode: with batch
+    # statistics over the goldens' two or three samples BatchNorm turns a rounding difference into a sign flip, so
+    # the train-mode outputs are not a meaningful yardstick for a reduced-precision pass.  bf16 carries 8 mantissa
+    # bits (2^-9 = 2e-3 relative per rounding) through ~10 layers: 5e-2 of the output's l2 norm.
+    _load(mod, z).to(dev).eval()
+    try:
+        nw.AUTOCAST = False
+        e32 = mod(x).detach().float().cpu().numpy()
+    finally:
+        nw.AUTOCAST = True
+    e16 = mod(x).detach().float().cpu().numpy()
+    rel = float(np.linalg.norm(e16 - e32) / max(np.linalg.norm(e32), 1e-12))
+    print(f"{name}: bf16 autocast vs fp32 on the GPU, eval mode: relative l2 error {rel:.2e}")
+    assert rel <= 5e-2, (name, rel)
+
+
+def _shapenet_like(b, n, m, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    v = torch.randn(b, n, 3, generator=g)
+    gt = 0.5 * v / v.norm(dim=2, keepdim=True)
+    partial = (gt[:, torch.randperm(n, generator=g)[:m]] + 1e-3 * torch.randn(b, m, 3, generator=g)).contiguous()
+    return partial.to(dev), gt.contiguous().to(dev)
+
+
+@pytest.mark.gpu
+def test_config4_full_size_step(dev):
+    """BASELINE config 4 at its stated sizes, one rank's share of the 8-GPU job: 4 clouds, 16384 output / 3000
+    input points, 32 primitives, hide 4096 (models/sparenet_generator.py:12-82, runners/sparenet_runner.py:83-108;
+    EMD metric, consistency loss): finite loss, finite gradient on EVERY parameter, Adam moves the weights; the
+    step time is printed (-s) for the record."""
+    import time
+    from sparenet_amd.harness import Completion
+
+    torch.manual_seed(0)
+    gen = nw.Generator(num_points=16384, n_primitives=32).to(dev)
+    assert sum(p.numel() for p in gen.parameters()) == 23_156_224 + 31_489_542 + 32 * 665_874 + 867_139
+    comp = Completion("emd", use_consist_loss=True, overlap=False).to(dev)
+    opt = torch.optim.Adam(gen.parameters(), lr=1e-4)
+    partial, gt = _shapenet_like(4, 16384, 3000, 1, dev)
+    before = [p.detach().clone() for p in gen.parameters()]
+    times = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss, refine, middle, coarse, refine_loss, coarse_loss = comp(gen, partial, gt)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gen.parameters())
+        opt.step()
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        assert torch.isfinite(loss) and refine.shape == middle.shape == coarse.shape == (4, 16384, 3)
+    assert any(not torch.equal(a, b) for a, b in zip(before, gen.parameters()))
+    print(f"config 4, 4 clouds on this rank: {min(times):.1f} ms per step (best of 3)")
+
+
+@pytest.mark.gpu
+def test_config5_full_size_gan_step(dev):
+    """BASELINE config 5 at its stated sizes, one rank's share (B = 64 over 8 GPUs = 8 clouds): generator +
+    8-view 256^2 renders of gt / middle / partial + PatchDiscriminator, both updates
+    (runners/sparenet_gan_runner.py:69-347): finite objectives, both networks move."""
+    import time
+    from sparenet_amd.harness import Completion, GanStep
+
+    torch.manual_seed(1)
+    gen = nw.Generator(num_points=16384, n_primitives=32).to(dev)
+    disc = nw.PatchDiscriminator((16, 256, 256)).to(dev)
+    step = GanStep(gen, disc, Completion("emd", overlap=False).to(dev), torch.optim.Adam(gen.parameters(), 1e-4),
+                   torch.optim.Adam(disc.parameters(), 1e-4))
+    partial, gt = _shapenet_like(8, 16384, 3000, 2, dev)
+    before_g = [p.detach().clone() for p in gen.parameters()]
+    before_d = [p.detach().clone() for p in disc.parameters()]
+    times = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = step(partial, gt)
+        torch.cuda.synchronize()
+        times.append((time.perf_counter() - t0) * 1e3)
+        assert all(torch.isfinite(out[k]).all() for k in ("rec_loss", "errG", "errG_D", "errD_real", "errD_fake"))
+    assert any(not torch.equal(a, b) for a, b in zip(before_g, gen.parameters()))
+    assert any(not torch.equal(a, b) for a, b in zip(before_d, disc.parameters()))
+    print(f"config 5, 8 clouds on this rank: {min(times):.1f} ms per step (best of 2)")
