@@ -56,6 +56,55 @@ void prof_end(const char *name, hipStream_t s) {
   g_open.erase(it);
 }
 
+namespace {
+struct Sticky {
+  unsigned *host = nullptr, *dev = nullptr;
+  bool tried = false;
+};
+std::mutex g_sticky_mu;
+Sticky g_sticky[64];
+}  // namespace
+
+unsigned *sticky_device_word(int dev) {
+  if (dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(g_sticky_mu);
+  Sticky &st = g_sticky[dev];
+  if (!st.tried) {
+    st.tried = true;
+    void *h = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
+      *static_cast<volatile unsigned *>(h) = 0u;
+      void *d = nullptr;
+      if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
+        st.host = static_cast<unsigned *>(h);
+        st.dev = static_cast<unsigned *>(d);
+      }
+    }
+    (void)hipGetLastError();
+  }
+  return st.dev;
+}
+
+int check_sticky(int dev, const char *what) {
+  if (dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lk(g_sticky_mu);
+  unsigned *w = g_sticky[dev].host;
+  if (w && *reinterpret_cast<volatile unsigned *>(w) != 0u) {
+    *reinterpret_cast<volatile unsigned *>(w) = 0u;
+    return fail(SN_ETIMEDOUT,
+                "%s: a bounded wait inside an EARLIER multi-workgroup launch on this device timed out (persistent EMD "
+                "auction or density sampler; the device is shared, or a debugger holds a compute unit); that call's "
+                "outputs were filled with NaN / -1 (EMD) or left incomplete (sampler)", what);
+  }
+  return 0;
+}
+
+void clear_sticky(int dev) {
+  if (dev < 0 || dev >= 64) return;
+  std::lock_guard<std::mutex> lk(g_sticky_mu);
+  if (g_sticky[dev].host) *reinterpret_cast<volatile unsigned *>(g_sticky[dev].host) = 0u;
+}
+
 }  // namespace sn
 
 extern "C" void sn_prof_enable(int on) { sn::g_prof.store(on != 0); }

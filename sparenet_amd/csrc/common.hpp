@@ -49,6 +49,13 @@ void prof_end(const char *name, hipStream_t s);
     if (sn::prof_enabled()) sn::prof_end(name, stream);    \
   } while (0)
 
+// Per-device sticky error word (pinned host memory, device-visible): a kernel whose workgroups wait for each other
+// (the persistent EMD auction, the multi-workgroup density sampler) sets it when a bounded wait gives up; the next
+// call of such an op on the device returns SN_ETIMEDOUT without a host synchronisation.
+unsigned *sticky_device_word(int dev);            // nullptr if the word could not be allocated
+int check_sticky(int dev, const char *what);      // 0, or SN_ETIMEDOUT (clears the word, fills sn_last_error)
+void clear_sticky(int dev);
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

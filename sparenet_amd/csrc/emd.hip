@@ -1535,8 +1535,6 @@ __global__ __launch_bounds__(64) void emd_litmus_kernel(unsigned *ctl, unsigned 
 struct DeviceState {
   int verified = 0;       // 0: not yet, 1: fence-free + XCD-local paths verified, 2: fall back (fenced, agent-scope stores)
   int tries = 0;
-  unsigned *sticky = nullptr;   // pinned host word, device-visible: a barrier of some launch gave up
-  unsigned *sticky_dev = nullptr;  // the same word as the device addresses it
   char why[160] = {0};
 };
 std::mutex g_dev_mu;
@@ -1610,22 +1608,6 @@ extern "C" int sn_emd_mode(void) {
   return g_dev[dev].verified == 1 ? 0 : -1;
 }
 
-namespace {
-// the sticky word of a device: set by a launch whose barrier gave up, reported (and cleared) by the next call
-int check_sticky(int dev, const char *what) {
-  std::lock_guard<std::mutex> lk(g_dev_mu);
-  unsigned *w = g_dev[dev].sticky;
-  if (w && *reinterpret_cast<volatile unsigned *>(w) != 0u) {
-    *reinterpret_cast<volatile unsigned *>(w) = 0u;
-    return sn::fail(SN_ETIMEDOUT,
-                    "%s: a team barrier of an EARLIER persistent auction launch on this device timed out (the device "
-                    "is shared, or a debugger holds a compute unit); that call's dist / assignment were filled with "
-                    "NaN / -1", what);
-  }
-  return 0;
-}
-}  // namespace
-
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
                               int iters, float *dist, int *assignment, void *workspace,
                               size_t workspace_bytes, long long *stats, void *stream) {
@@ -1641,28 +1623,15 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   int dev = 0, cus = 0;
   SN_HIP(hipGetDevice(&dev));
   SN_REQUIRE(dev >= 0 && dev < 64, "sn_emd_forward: unexpected device ordinal %d", dev);
-  if (const int rc = check_sticky(dev, "sn_emd_forward")) return rc;
+  if (const int rc = sn::check_sticky(dev, "sn_emd_forward")) return rc;
   SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   SN_REQUIRE(cus >= 1 && cus <= 1024, "sn_emd_forward: unexpected compute-unit count %d", cus);
   const char *safe_env = getenv("SN_EMD_SAFE");   // read per call: tests switch it inside one process
   int safe = safe_env && safe_env[0] == '1';
-  unsigned *sticky = nullptr;
+  unsigned *sticky = sn::sticky_device_word(dev);
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     DeviceState &st = g_dev[dev];
-    if (!st.sticky) {
-      void *h = nullptr;
-      if (hipHostMalloc(&h, 64, hipHostMallocMapped) == hipSuccess) {
-        *static_cast<unsigned *>(h) = 0u;
-        void *d = nullptr;
-        if (hipHostGetDevicePointer(&d, h, 0) == hipSuccess && d) {
-          st.sticky = static_cast<unsigned *>(h);
-          st.sticky_dev = static_cast<unsigned *>(d);
-        }
-      }
-      (void)hipGetLastError();
-    }
-    sticky = st.sticky_dev;
     if (!safe && st.verified == 0) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(s, &cap);
@@ -1717,10 +1686,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
       unsigned abort_word = 0;
       SN_HIP(hipStreamSynchronize(s));
       SN_HIP(hipMemcpy(&abort_word, &args.ctl->abort, 4, hipMemcpyDeviceToHost));
-      if (abort_word != 0) {
-        std::lock_guard<std::mutex> lk(g_dev_mu);
-        if (g_dev[dev].sticky) *reinterpret_cast<volatile unsigned *>(g_dev[dev].sticky) = 0u;
-      }
+      if (abort_word != 0) sn::clear_sticky(dev);
       SN_REQUIRE(abort_word == 0, "sn_emd_forward: a team barrier of the persistent auction timed out");
     }
     return sn::launch_status("sn_emd_forward");
@@ -1736,7 +1702,7 @@ extern "C" int sn_emd_backward(const float *xyz1, const float *xyz2, const float
     int dev = 0;
     SN_HIP(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64)
-      if (const int rc = check_sticky(dev, "sn_emd_backward")) return rc;
+      if (const int rc = sn::check_sticky(dev, "sn_emd_backward")) return rc;
   }
   const long total = (long)b * n;
   const int blocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);

@@ -18,6 +18,8 @@
 // (float)((double)temp + w) equals the plain fp32 sum for every pair of floats
 // (the double sum is exact unless w < ulp(temp)/32, where both round to temp), so
 // the accumulation stays in fp32.
+#include <cstdlib>
+
 #include "cloud_sort.hpp"
 #include "common.hpp"
 #include "../../include/sn_expf.h"
@@ -211,7 +213,7 @@ template <int PPT>
 __global__ __launch_bounds__(1024) void mds_clustered_kernel(
     int n, int m, const float *__restrict__ xyz, const int *__restrict__ perm_all,
     const float *__restrict__ bbox, const float *__restrict__ mean_mst_length,
-    int *__restrict__ idxs) {
+    int *__restrict__ idxs, float team_ratio) {
 #pragma clang fp contract(off)
   extern __shared__ __attribute__((aligned(16))) float yz[];  // [PPT*1024][2], lane private
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -230,6 +232,8 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
     diag2 += ext * ext;
   }
   const bool fast_div = t >= 0x1p-40f && t <= 0x1p40f && diag2 * rt < 0x1p100f;
+  // dense regime (the cut ball covers most of the cloud): done by mds_dense_team_kernel when it was launched
+  if (team_ratio > 0.f && cut2 > team_ratio * diag2) return;
 
   float px[PPT], tmp[PPT];
   unsigned low[PPT];  // (bitrev10(k mod 1024) << 16) | (k << 1) | (k >= 8192), ~0 for padding
@@ -472,6 +476,282 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense regime on a TEAM of workgroups (mds_dense_team_kernel).
+// When the cut ball covers most of the cloud every slot is updated in every round and a round is bound by the
+// vector ALUs of the ONE compute unit that owns the cloud (4.3 us x 16383 rounds = 68 ms at n = 19384, whatever
+// the batch: 32 of 256 CUs busy at B = 32, 4 at the 8-GPU share).  Here G workgroups share a cloud: workgroup g
+// keeps the slots [g PG, (g + 1) PG) of the cluster-sorted cloud, updates them, finds its own arg-min exactly as
+// the single-workgroup kernel does, and the G candidates meet in global memory:
+//   * one 64-bit word per workgroup and round, {density bits : 32 | low key : 26 | round stamp : 6}, in a ring of
+//     two rounds, written with ONE agent-scope store and polled with agent-scope loads by lanes 0 .. G-1 of every
+//     wave (a word is either entirely of this round or not: no fence, no flag + data pair);
+//   * the minimum over the G words (density, then the reference's tie key) is the pick; its coordinates are read
+//     from xyz (constant data, one uniform load).
+//   A workgroup can only run two rounds ahead of the slowest member (round j + 1 needs everybody's round-j word),
+//   so the two-deep ring never overwrites a word somebody still needs.
+// Teams are formed from XCD-local tickets like the auction's (emd.hip): the G workgroups of a cloud sit on one
+// XCD whenever the dispatcher allows it, so the words travel through that XCD's L2; any placement is correct.
+// Every poll is bounded: on a time-out the launch raises its abort word and the device's sticky word (the next
+// sn_mds / sn_emd_* call fails with SN_ETIMEDOUT), and the indices not yet picked are written as 0.
+// Only clouds in the dense regime take this path (the predicate is the single-workgroup kernel's, which skips
+// exactly those clouds); index sequences are identical by construction -- the arg-min is order independent.
+// ---------------------------------------------------------------------------------------
+struct MdsTeamCtl {          // zeroed before the launch
+  unsigned xticket[8];
+  unsigned ticket;
+  unsigned abort;
+  unsigned pad[22];
+  unsigned long long words[1];  // [teams][3][G] x kWordStride: two ring slots + the formation slot, one line each
+};
+constexpr int kWordStride = 16;  // 128 bytes: every member's word in its own cache line
+
+template <int PG>
+__global__ __launch_bounds__(1024) void mds_dense_team_kernel(
+    int B, int n, int m, const float *__restrict__ xyz, const int *__restrict__ perm_all,
+    const float *__restrict__ bbox, const float *__restrict__ mean_mst_length, int *__restrict__ idxs,
+    MdsTeamCtl *ctl, unsigned *sticky, int G, int teams, int xcd_local, unsigned spin_limit, float team_ratio) {
+#pragma clang fp contract(off)
+  extern __shared__ __attribute__((aligned(16))) float yz[];  // [PG*1024][2], lane private
+  __shared__ int s_ticket;
+  __shared__ unsigned wave_val[2][16];
+  __shared__ float4 wave_pick[2][16];  // x, y, z, low bits
+  __shared__ float4 s_pick[2];         // the team's pick of the round: x, y, z, low bits
+  __shared__ int s_state[2], s_stray;  // 1: a pick, 0: nothing below 1e9 anywhere, -1: a member never answered
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (tid == 0) {
+    int t = -1;
+    s_stray = 0;
+    if (xcd_local) {
+      const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);  // HW_REG_XCC_ID
+      const int cap = (teams / 8) * G;
+      for (int i = 0; i < 9 && t < 0; ++i) {
+        const int x = (xcc + i) & 7;
+        const int k = (int)__hip_atomic_fetch_add(&ctl->xticket[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k < cap) {
+          t = ((k / G) * 8 + x) * G + k % G;
+          s_stray = i != 0;  // a slot of another XCD's team
+        }
+      }
+    } else {
+      s_stray = 1;
+      t = (int)__hip_atomic_fetch_add(&ctl->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    s_ticket = t;
+  }
+  __syncthreads();
+  const int ticket = s_ticket;
+  if (ticket < 0) return;
+  const int b = ticket / G, g = ticket % G;
+  if (b >= B || b >= teams) return;
+  const float *__restrict__ p = xyz + (size_t)b * n * 3;
+  const int *__restrict__ perm = perm_all + (size_t)b * n;
+  int *__restrict__ out = idxs + (size_t)b * m;
+  const float mml = mean_mst_length[b];
+  const float t = (float)(5.0 * (double)mml * (double)mml);
+  const float cut2 = 104.0f * t * 1.0001f;
+  const float rt = 1.0f / t;
+  float diag2 = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ext = bbox[b * 6 + 3 + a] - bbox[b * 6 + a];
+    diag2 += ext * ext;
+  }
+  if (!(cut2 > team_ratio * diag2)) return;  // not dense enough: the single-workgroup kernel owns this cloud
+  const bool fast_div = t >= 0x1p-40f && t <= 0x1p40f && diag2 * rt < 0x1p100f;
+  const float far2 = cut2 * 1.001f;
+
+  float px[PG], tmp[PG];
+  unsigned low[PG];
+  float blx = 3e38f, bly = 3e38f, blz = 3e38f, bhx = -3e38f, bhy = -3e38f, bhz = -3e38f;
+#pragma unroll
+  for (int i = 0; i < PG; ++i) {
+    const int s = (((g * PG + i) * 16 + wave) << 6) + lane;  // sorted position: slot g PG + i of the one-workgroup layout
+    const bool valid = s < n;
+    const int k = valid ? perm[s] : 0;
+    const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
+    px[i] = valid ? x : 0.f;
+    yz[2 * (i * 1024 + tid) + 0] = valid ? y : 0.f;
+    yz[2 * (i * 1024 + tid) + 1] = valid ? z : 0.f;
+    tmp[i] = valid ? 0.f : 1e9f;
+    low[i] = valid ? ((__brev((unsigned)(k & 1023)) >> 22) << 16) | ((unsigned)k << 1) | (k >= 8192 ? 1u : 0u)
+                   : 0xffffffffu;
+    float lx = valid ? x : 3e38f, ly = valid ? y : 3e38f, lz = valid ? z : 3e38f;
+    float hx = valid ? x : -3e38f, hy = valid ? y : -3e38f, hz = valid ? z : -3e38f;
+    for (int mm = 1; mm < 64; mm <<= 1) {
+      lx = __builtin_fminf(lx, __shfl_xor(lx, mm));
+      ly = __builtin_fminf(ly, __shfl_xor(ly, mm));
+      lz = __builtin_fminf(lz, __shfl_xor(lz, mm));
+      hx = __builtin_fmaxf(hx, __shfl_xor(hx, mm));
+      hy = __builtin_fmaxf(hy, __shfl_xor(hy, mm));
+      hz = __builtin_fmaxf(hz, __shfl_xor(hz, mm));
+    }
+    if (lane == i) {
+      blx = lx, bly = ly, blz = lz;
+      bhx = hx, bhy = hy, bhz = hz;
+    }
+  }
+  int last = 0;
+  if (tid == 0 && g == 0) out[0] = 0;
+  const unsigned kBig = __float_as_uint(1e9f);
+  const float x0 = p[0], y0 = p[1], z0 = p[2];
+  float x1 = x0, y1 = y0, z1 = z0;
+  unsigned last_low = 0;  // low bits of point 0
+  unsigned long long *words = ctl->words + (size_t)b * 3 * G * kWordStride;   // [2 ring slots + 1 formation slot][G]
+  // Is the whole team on one XCD?  Every member says whether it took a slot of another XCD's team (agent-scope
+  // words, round stamp 63 -- the rounds start at 1), then everybody knows.
+  bool loc = false;
+  {
+    if (wave == 0) {
+      unsigned long long *slot = words + ((size_t)2 * G) * kWordStride;
+      if (lane == 0)
+        __hip_atomic_store(&slot[(size_t)g * kWordStride], 63ull | ((unsigned long long)s_stray << 6), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long w = 63ull | ((unsigned long long)s_stray << 6);
+      if (lane < G && lane != g) {
+        unsigned spins = 0;
+        for (;;) {
+          w = __hip_atomic_load(&slot[(size_t)lane * kWordStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((w & 63ull) == 63ull) break;
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > spin_limit) {
+            __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+          }
+          if ((spins & 1023u) == 0u && __hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        }
+      }
+      const bool missing = lane < G && (w & 63ull) != 63ull;
+      const bool strayed = lane < G && ((w >> 6) & 1ull) != 0ull;
+      if (lane == 0) s_state[0] = __any(missing) ? -1 : (__any(strayed) ? 0 : 1);
+    }
+    __syncthreads();
+    if (s_state[0] < 0) {
+      if (g == 0)
+        for (int e = tid; e < m; e += 1024) out[e] = 0;
+      return;
+    }
+    loc = s_state[0] == 1;
+    __syncthreads();
+  }
+
+  for (int j = 1; j < m; ++j) {
+    const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
+    const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
+    const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
+    const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
+    unsigned mn = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < PG; ++i) {
+      if ((mask >> i) & 1u) {  // wave-uniform
+        const float v = (low[i] == last_low) ? 1e9f : tmp[i];
+        const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
+        const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
+        tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
+      }  // (the pick's own slot is always inside the ball: its 1e9 mark is never skipped)
+      mn = umin32(mn, __float_as_uint(tmp[i]));
+    }
+    // arg-min of (density, low) inside the wave: the full key comparison (PG is small)
+    const unsigned wm = wave_min_u32(mn);
+    unsigned wl = 0xffffffffu;
+    float wx = 0.f;
+    int wi = 0;
+#pragma unroll
+    for (int i = 0; i < PG; ++i) {
+      const bool lt = __float_as_uint(tmp[i]) == wm && low[i] < wl;
+      wl = lt ? low[i] : wl;
+      wx = lt ? px[i] : wx;
+      wi = lt ? i : wi;
+    }
+    const unsigned wlmin = wave_min_u32(wl);
+    const bool winner = wl == wlmin && wl != 0xffffffffu;  // lows of real points are unique
+    const int buf = j & 1;
+    if (lane == 0) wave_val[buf][wave] = wm;
+    if (winner) {
+      const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
+      wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
+    }
+    __syncthreads();
+    const int l16 = lane & 15;
+    const unsigned v16 = wave_val[buf][l16];
+    const float4 pk = wave_pick[buf][l16];
+    const unsigned minv = row_min_u32(v16);
+    const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
+    const unsigned minl = row_min_u32(lw);
+    // this workgroup's candidate: (minv, minl); "nothing below 1e9" travels as (>= kBig, all ones)
+    if (wave == 0) {  // ONE wave per workgroup talks to the others (sixteen pollers per workgroup on the same lines
+                      // slowed every store down); the rest of the workgroup waits at the barrier below
+      const unsigned my_val = (unsigned)__builtin_amdgcn_readfirstlane((int)minv);
+      const unsigned my_low = my_val >= kBig ? 0x3ffffffu : ((unsigned)__builtin_amdgcn_readfirstlane((int)minl) & 0x3ffffffu);
+      const unsigned long long mine =
+          ((unsigned long long)my_val << 32) | ((unsigned long long)my_low << 6) | (unsigned long long)(j & 63);
+      unsigned long long *slot = words + ((size_t)buf * G) * kWordStride;
+      if (lane == 0) {
+        // a team on ONE XCD keeps its words in that XCD's L2 (plain store; the pollers' coherent loads meet it
+        // there); an agent-scope store goes out to the fabric and takes the line with it
+        if (loc)
+          __hip_atomic_store(&slot[(size_t)g * kWordStride], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+          __hip_atomic_store(&slot[(size_t)g * kWordStride], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      unsigned long long w = mine;
+      if (lane < G && lane != g) {
+        unsigned spins = 0;
+        for (;;) {
+          w = __hip_atomic_load(&slot[(size_t)lane * kWordStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)(w & 63ull) == (unsigned)(j & 63)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((++spins & 1023u) == 0u) {
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (spins > spin_limit) {
+              __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              break;
+            }
+          }
+        }
+      }
+      const bool stale = lane < G && (unsigned)(w & 63ull) != (unsigned)(j & 63);
+      unsigned long long key = lane < G ? (w >> 6) : ~0ull;
+#pragma unroll
+      for (int sft = 1; sft < 16; sft <<= 1) {  // G <= 16
+        const unsigned long long o = shfl_xor_u64(key, sft, 16);
+        key = o < key ? o : key;
+      }
+      const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key >> 32));
+      const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)key);
+      const unsigned long long kmin = ((unsigned long long)khi << 32) | klo;
+      const unsigned val = (unsigned)(kmin >> 26);
+      const unsigned lw2 = (unsigned)(kmin & 0x3ffffffull);
+      const int k = val >= kBig ? 0 : (int)((lw2 >> 1) & 0x7fffu);
+      const float px_ = p[k * 3 + 0], py_ = p[k * 3 + 1], pz_ = p[k * 3 + 2];  // uniform address, constant data
+      if (lane == 0) {
+        s_pick[buf] = make_float4(px_, py_, pz_, __uint_as_float(val >= kBig ? 0u : lw2));
+        s_state[buf] = __any(stale) ? -1 : (val >= kBig ? 0 : 1);
+      }
+    }
+    __syncthreads();
+    const int state = s_state[buf];
+    if (state < 0) {  // a member never answered: leave valid indices behind and go (workgroup-uniform)
+      if (g == 0)
+        for (int e = j + tid; e < m; e += 1024) out[e] = 0;
+      return;
+    }
+    {
+      const float4 pk2 = s_pick[buf];
+      last_low = __float_as_uint(pk2.w);
+      last = state ? (int)((last_low >> 1) & 0x7fffu) : 0;  // state 0: nothing below 1e9 anywhere -> (1e9, index 0)
+      x1 = pk2.x;
+      y1 = pk2.y;
+      z1 = pk2.z;
+    }
+    if (tid == 0 && g == 0) out[j] = last;
+  }
+}
+
 // generic fallback for clouds that do not fit the register budget: state in global memory
 __global__ __launch_bounds__(1024) void mds_kernel_generic(int n, int m,
                                                            const float *__restrict__ xyz,
@@ -570,10 +850,13 @@ static bool mds_use_clustered(int n) {
   return n >= 2048 && (size_t)((n + 1023) / 1024) * 8192 + 1024 <= 160 * 1024;
 }
 
+constexpr size_t kMdsTeamCtlBytes = 128 + 128 * 3 * 1024;  // header + exchange lines of up to 1024 team members
+
 extern "C" size_t sn_mds_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  if (mds_use_clustered(n))  // perm + cell ids + cell offsets + bounding boxes
-    return sn::align_up((size_t)b * n * 4, 256) * 2 + (size_t)b * kSortCells * 4 + 256 * (size_t)b;
+  if (mds_use_clustered(n))  // perm + cell ids + cell offsets + bounding boxes + the dense-regime teams' control block
+    return sn::align_up((size_t)b * n * 4, 256) * 2 + (size_t)b * kSortCells * 4 + sn::align_up(256 * (size_t)b, 256) +
+           kMdsTeamCtlBytes;
   int bs = 1;
   while (bs * 2 <= n && bs < 1024) bs *= 2;
   return (n + bs - 1) / bs <= 24 ? 0 : (size_t)b * n * 4;
@@ -600,8 +883,57 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     int *perm = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
     int *cell_of = reinterpret_cast<int *>(w); w += sn::align_up((size_t)b * n * 4, 256);
     int *hist = reinterpret_cast<int *>(w); w += (size_t)b * kSortCells * 4;
-    float *bbox = reinterpret_cast<float *>(w);
+    float *bbox = reinterpret_cast<float *>(w); w += sn::align_up(256 * (size_t)b, 256);
+    MdsTeamCtl *tctl = reinterpret_cast<MdsTeamCtl *>(w);
     SN_REQUIRE(cloud_sort(b, n, xyz, bbox, hist, cell_of, perm, s) == 0, "sn_mds: cannot size the sort kernel's LDS");
+    // Dense-regime clouds go to a team of G workgroups each (mds_dense_team_kernel); the one-workgroup kernel below
+    // then skips them.  G = the largest power of two <= 16 such that every cloud's team fits one XCD's share of the
+    // compute units and the whole grid is resident (the members wait for each other); SN_MDS_G overrides (1: off).
+    // Measured at n = 19384 -> 16384 (profiles/r03_*_mds_teams.txt): a team round costs ~1.9 us (G = 8) / 1.7 us
+    // (G = 16) whatever the regime, the one-workgroup kernel 1.1 us (surface) ... 4.3 us (cut ball = the cloud);
+    // the two cross where the cut ball's squared radius is ~0.15 of the box diagonal's.
+    int team_g = 1, team_slots = 0;
+    // a cloud goes to a team when its cut ball's squared radius exceeds this fraction of the squared diagonal of
+    // its bounding box (SN_MDS_RATIO; measured cross-over)
+    static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.12f; return v > 0.f ? v : 0.12f; }();
+    {
+      int dev = 0, cus = 0;
+      SN_HIP(hipGetDevice(&dev));
+      if (const int rc = sn::check_sticky(dev, "sn_mds")) return rc;
+      SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      static const int gmax = [] { const char *e = getenv("SN_MDS_G"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 16 ? v : 16; }();
+      if (cus >= 64 && cus % 8 == 0 && ppt >= 2) {
+        const int per = cus / 8, tpx = (b + 7) / 8;
+        int g = 1;
+        while (g * 2 * tpx <= per && g * 2 <= gmax && g * 2 <= ppt) g *= 2;
+        team_g = g;
+        team_slots = 8 * tpx;
+      }
+      if (team_g >= 2) {
+        const int pg = (ppt + team_g - 1) / team_g;
+        unsigned *sticky = sn::sticky_device_word(dev);
+        SN_REQUIRE(team_slots * team_g <= 1024, "sn_mds: unexpected team geometry");
+        SN_HIP(hipMemsetAsync(tctl, 0, 128 + 128 * 3 * (size_t)team_slots * team_g, s));
+#define SN_MDST(P)                                                                                          \
+  {                                                                                                         \
+    SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_dense_team_kernel<P>),                   \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));             \
+    mds_dense_team_kernel<P><<<team_slots * team_g, 1024, (size_t)P * 8192, s>>>(                           \
+        b, n, m, xyz, perm, bbox, mean_mst_length, idx, tctl, sticky, team_g, team_slots, 1, 1u << 24,      \
+        team_ratio);                                                                                        \
+  }
+        if (pg <= 1) SN_MDST(1)
+        else if (pg <= 2) SN_MDST(2)
+        else if (pg <= 3) SN_MDST(3)
+        else if (pg <= 4) SN_MDST(4)
+        else if (pg <= 5) SN_MDST(5)
+        else if (pg <= 6) SN_MDST(6)
+        else if (pg <= 8) SN_MDST(8)
+        else SN_MDST(10)
+#undef SN_MDST
+      }
+    }
+    const float skip_ratio = team_g >= 2 ? team_ratio : 0.f;
     const size_t lds = (size_t)ppt * 1024 * 8;
 #define SN_MDSC(P)                                                                               \
   {                                                                                              \
@@ -609,7 +941,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
        DataParallel), it is not a per-process fact */                                            \
     SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_clustered_kernel<P>),         \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));  \
-    mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, bbox, mean_mst_length, idx);          \
+    mds_clustered_kernel<P><<<b, 1024, lds, s>>>(n, m, xyz, perm, bbox, mean_mst_length, idx, skip_ratio); \
   }
     // exact slot counts near the register limit (19 at SpareNet's n = 19384): every unused
     // slot costs three VGPRs and the 1024-lane workgroup only has 128 per lane

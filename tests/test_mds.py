@@ -194,3 +194,21 @@ def test_hip_full_length_on_surface_clouds(kind, mml, dev):
         x = (pick + 0.03 * rng.standard_normal((1, n, 3)).astype(np.float32)).astype(np.float32)
     mm = np.array([mml], np.float32)
     assert np.array_equal(_hip_mds(x, m, mm, dev), oracle.mds(x, m, mm, exp_mode=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,m", [(1, 19384, 3000), (5, 19384, 2500), (12, 6000, 3000), (33, 4096, 2000),
+                                   (70, 2048, 1500)])
+def test_hip_dense_regime_teams_and_mixed_batches(b, n, m, dev):
+    """Clouds whose cut ball covers a good part of their bounding box are sampled by a TEAM of workgroups
+    (mds_dense_team_kernel: 16 / 8 / 4 / 2 workgroups per cloud depending on the batch, candidates exchanged through
+    stamped 64-bit words), the others by the one-workgroup kernel -- in ONE call when a batch mixes both.  The batch
+    here alternates mean MST lengths on both sides of the cross-over; every row must equal the oracle's sequence."""
+    rng = np.random.default_rng(b * 1000 + n)
+    x = rng.random((b, n, 3), dtype=np.float32)
+    mm = np.where(np.arange(b) % 2 == 0, 0.09, 0.012).astype(np.float32) * (1 + 0.2 * rng.random(b, dtype=np.float32))
+    got = _hip_mds(x, m, mm, dev)
+    want = oracle.mds(x, m, mm, exp_mode=1)
+    assert np.array_equal(got, want)
+    got2 = _hip_mds(x, m, mm, dev)          # run to run: the exchange is deterministic
+    assert np.array_equal(got, got2)
