@@ -198,9 +198,13 @@ class HotPath:
         return acc
 
     def step_overlapped(self, pred, gt):
-        """The same step with the renderer on a second HIP stream: the four parts are independent
-        given the predicted cloud, and the renderer's kernels fill the CUs the late (few-bidder) auction
-        iterations leave idle.  Same kernels, same results; per-kernel durations stretch under contention."""
+        """The same step with the renderer on a second HIP stream: the four parts are independent given the
+        predicted cloud; the renderer overlaps the expansion penalty, Chamfer and the auction's preparation (the
+        persistent auction itself owns every CU it runs on).  Same kernels, same results; per-kernel durations
+        stretch under contention.  (Measured and not kept, r03: at <= 8 clouds per rank the auction's XCD-local
+        teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
+        SLOWER, 2.54 vs 2.23 ms at 4 clouds -- the auction's workgroups then start late on busy CUs and its teams
+        wait for them.)"""
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream()
@@ -216,25 +220,37 @@ class HotPath:
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
         return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
 
-    def _distance_losses(self, pred, gt, mark=lambda name: None):
-        # The expansion penalty first: one wave per 512-point patch = one lone wave per SIMD for 0.45 ms,
-        # latency bound -- next to the renderer's stream it costs nothing, at the end of the chain it runs alone.
+    def _loss_expansion(self, pred):
+        # one wave per 512-point patch = lone waves for 0.35-0.45 ms, latency bound: next to another stream's work
+        # it costs nothing, at the end of a chain it runs alone
         p3 = pred.detach().requires_grad_(True)
         pen, _, mml = self.expansion(p3, PRIM, ALPHA)
         loss_exp = pen.mean()
         loss_exp.backward()
         self.last_mean_mst = mml.detach()
-        mark("expansion")
+        return loss_exp
+
+    def _loss_cd(self, pred, gt):
         p = pred.detach().requires_grad_(True)
         g = gt.detach().requires_grad_(True)
         d1, d2 = self.cd(p, g)
         loss_cd = d1.mean() + d2.mean()
         loss_cd.backward()
-        mark("cd")
+        return loss_cd
+
+    def _loss_emd(self, pred, gt):
         p2 = pred.detach().requires_grad_(True)
         dist_, _ = self._emd(p2, gt)
         loss_emd = torch.sqrt(dist_).mean(1).mean()
         loss_emd.backward()
+        return loss_emd
+
+    def _distance_losses(self, pred, gt, mark=lambda name: None):
+        loss_exp = self._loss_expansion(pred)
+        mark("expansion")
+        loss_cd = self._loss_cd(pred, gt)
+        mark("cd")
+        loss_emd = self._loss_emd(pred, gt)
         mark("emd")
         return loss_cd, loss_emd, loss_exp
 

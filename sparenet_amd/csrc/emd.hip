@@ -33,6 +33,7 @@
 //     (atomic exchange on the target's head word); after ONE team barrier the list's head walks it, applies the
 //     reference's +-1e-6 window and its highest-bidder-index rule, awards the target and re-flags the losers.
 //     Two team barriers per iteration instead of three, no separate GetMax pass.
+#include <atomic>
 #include <cstdlib>
 #include <mutex>
 
