@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true",
                     help="time the sequential one-stream step instead of the two-stream one")
+    ap.add_argument("--no-network-steps", action="store_true",
+                    help="skip the BASELINE config 4 / 5 step timings (sparenet_amd/networks.py), N = 1 only")
     ap.add_argument("--no-other-ops", action="store_true",
                     help="skip the untimed-for-the-headline MDS/gather/gridding/cubic measurements")
     ap.add_argument("--per-view-render", action="store_true",
@@ -203,8 +205,7 @@ class HotPath:
         persistent auction itself owns every CU it runs on).  Same kernels, same results; per-kernel durations
         stretch under contention.  (Measured and not kept, r03: at <= 8 clouds per rank the auction's XCD-local
         teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
-        SLOWER, 2.54 vs 2.23 ms at 4 clouds -- the auction's workgroups then start late on busy CUs and its teams
-        wait for them.)"""
+        SLOWER whichever side was enqueued first: 2.52-2.54 vs 2.26 ms at 4 clouds, 2.86 vs 2.54 at 8.)"""
         main = torch.cuda.current_stream()
         if self.side is None:
             self.side = torch.cuda.Stream()
@@ -407,10 +408,7 @@ def other_ops(dev, pred, mean_mst):
     # (what a decoder's primitives look like) + 3000 points of the partial input; the expansion's
     # own mean_mst_length is then ~0.01 instead of ~0.05 and the cut radius covers ~5 % of the cloud
     from sparenet_amd.cuda.expansion_penalty.expansion_penalty_module import expansionPenaltyModule
-    v = torch.randn(B, N, 3, generator=g)
-    v = 0.5 * v / v.norm(dim=2, keepdim=True)
-    key = (torch.atan2(v[..., 1], v[..., 0]) * 4).floor() * 100 + (v[..., 2] * 8).floor()
-    surf = torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous().to(dev)
+    surf = surface_like(B, N, g).to(dev)
     _, _, mml_s = expansionPenaltyModule()(surf, PRIM, ALPHA)
     cloud_s = torch.cat([surf, surf[:, :3000] + 0.01 * torch.randn(B, 3000, 3, generator=g).to(dev)],
                         dim=1).contiguous()
@@ -452,6 +450,72 @@ def other_ops(dev, pred, mean_mst):
     def graph_fb():
         get_graph_feature(xf, k=8, idx=nbr).sum().backward()
     out["graph_feature_c256_fwd_bwd"] = ms(graph_fb)
+    return out
+
+
+def surface_like(b, n, g):
+    """[b, n, 3] points on a sphere of radius 0.5, ordered so that every run of 512 consecutive points is a compact
+    patch -- what a trained decoder's 32 primitives look like (mean MST length ~0.01 instead of ~0.08 on a uniform
+    cube: the sampler's surface regime)."""
+    v = torch.randn(b, n, 3, generator=g)
+    v = 0.5 * v / v.norm(dim=2, keepdim=True)
+    key = (torch.atan2(v[..., 1], v[..., 0]) * 4).floor() * 100 + (v[..., 2] * 8).floor()
+    return torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+
+
+def network_steps(dev):
+    """BASELINE configs 4-5 at their stated sizes (16384 output / 3000 input points, 32 primitives, hide 4096), one
+    rank's share of the 8-GPU job (4 resp. 8 clouds), with the reference's networks restated in
+    sparenet_amd/networks.py (bf16 autocast around the fp32 HIP ops) -- outside the headline region, for the
+    record.  Two decoder states each, because the sampler's regime depends on the coarse cloud: `random_init`
+    (the decoder's output fills the cube: dense regime) and `trained_stand_in` (the decoder's output replaced by a
+    surface-like cloud, its own computation kept in the graph with weight 0: what a trained decoder produces)."""
+    from sparenet_amd import networks as nw
+    from sparenet_amd.harness import Completion, GanStep
+
+    class _StandIn(torch.nn.Module):
+        def __init__(self, dec, surf):
+            super().__init__()
+            self.dec, self.surf = dec, surf
+
+        def forward(self, style):
+            return self.surf + 0.0 * self.dec(style)
+
+    def clock(fn, reps=2):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    g = torch.Generator().manual_seed(4)
+    out = {}
+    for cfg, b in (("config4", 4), ("config5", 8)):
+        gt = surface_like(b, N, g).to(dev)
+        partial = (gt[:, torch.randperm(N, generator=g)[:3000]] + 1e-3 * torch.randn(b, 3000, 3, generator=g).to(dev)).contiguous()
+        for state in ("random_init", "trained_stand_in"):
+            torch.manual_seed(0)
+            gen = nw.Generator(num_points=N, n_primitives=32).to(dev)
+            if state == "trained_stand_in":
+                gen.decoder = _StandIn(gen.decoder, (gt + 0.01 * torch.randn(b, N, 3, generator=g).to(dev)).transpose(1, 2).contiguous())
+            opt_g = torch.optim.Adam(gen.parameters(), lr=1e-4)
+            comp = Completion("emd", overlap=False).to(dev)
+            if cfg == "config4":
+                def step():
+                    loss, *_ = comp(gen, partial, gt)
+                    opt_g.zero_grad(set_to_none=True)
+                    loss.backward()
+                    opt_g.step()
+            else:
+                disc = nw.PatchDiscriminator((16, IMG, IMG)).to(dev)
+                gan = GanStep(gen, disc, comp, opt_g, torch.optim.Adam(disc.parameters(), lr=1e-4))
+                step = lambda: gan(partial, gt)
+            out[f"step_ms_{cfg}_{state}"] = clock(step)
+            del gen, opt_g
+    out["note"] = ("one rank's share of the 8-GPU job: config 4 = 4 clouds (global batch 32), config 5 = 8 clouds (global "
+                   "batch 64); EMD metric; forward + backward + optimiser step(s)")
     return out
 
 
@@ -780,6 +844,8 @@ def main():
                 blk.update(cbm)
                 blk["frac"] = cbm.get("executed_frac")      # counters are taken on the surface-like cloud
                 roofline["mds_clustered"] = blk
+        if world == 1 and not args.no_network_steps:
+            out["network_steps_rank0"] = network_steps(dev)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             # the north star's combined ratio: one step's forward work, CPU over the GPU's whole step

@@ -6,6 +6,9 @@ import bench
 
 dev = torch.device("cuda:0")
 pred, gt = bench.make_inputs(dev, 0, 1, "weak")
+b = int(os.environ.get("HO_B", "32"))      # HO_B=4: the 8-GPU strong-scaling share
+pred, gt = pred[:b].contiguous(), gt[:b].contiguous()
+print(f"clouds per step: {b}")
 hp = bench.HotPath(dev, [5.0, 7.0, 10.0])
 for _ in range(5):
     hp.step_overlapped(pred, gt)
