@@ -204,11 +204,19 @@ __global__ __launch_bounds__(kThreads) void chamfer_fwd_kernel(
 // integer atomics (count -> scan -> fill; the fill order is arbitrary, so every list is sorted before it is
 // used) and each point then adds its terms in exactly the order above: no floating-point atomic, results
 // bit-reproducible and bit-equal to the reference's own CPU build.
+// a neighbour index from the caller (cd.backward_cuda takes idx tensors): out-of-range values would address LDS /
+// the lists out of bounds, so they are clamped (the forward never produces one)
+__device__ __forceinline__ int clamp_idx(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+constexpr int kLongList = 64;      // inverse lists longer than this are sorted and summed by a workgroup
+constexpr int kLongSortCap = 16384;  // ... in LDS up to this length (64 KB); longer ones by one thread, in place
+
 struct BwdLists {
   int *cnt;    // [B, N + M]  how many points of the other cloud chose me (entries 0..N-1: cloud 1, then cloud 2)
   int *off;    // [B, N + M]  list start
   int *fill;   // [B, N + M]  next free slot while filling
   int *list;   // [B, N + M]  the inverse lists: lists of cloud-1 points hold indices k of cloud 2 and vice versa
+  int *longs;  // [1 + B (N + M) / 64]  count, then the global slots (b (N + M) + slot) of the lists > kLongList
 };
 
 __global__ __launch_bounds__(256) void chamfer_bwd_count_kernel(const int *__restrict__ idx1,
@@ -221,14 +229,15 @@ __global__ __launch_bounds__(256) void chamfer_bwd_count_kernel(const int *__res
     const long f = second ? e - total1 : e;
     const int b = (int)(f / (second ? M : N));
     // a cloud-1 query j votes for cloud-2 point idx1[j] (slot N + idx1[j]); a cloud-2 query for slot idx2[k]
-    const int slot = second ? idx2[f] : N + idx1[f];
+    const int slot = second ? clamp_idx(idx2[f], N) : N + clamp_idx(idx1[f], M);
     atomicAdd(&cnt[(long)b * NM + slot], 1);
   }
 }
 
 // exclusive scan of the counts of one cloud (both sides in one sequence); also primes the fill cursors
 __global__ __launch_bounds__(1024) void chamfer_bwd_scan_kernel(int NM, const int *__restrict__ cnt,
-                                                               int *__restrict__ off, int *__restrict__ fill) {
+                                                               int *__restrict__ off, int *__restrict__ fill,
+                                                               int *__restrict__ longs) {
   __shared__ int wsum[16];
   __shared__ int carry;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_scan_kernel(int NM, const in
     if (i < NM) {
       off[o + i] = pre + incl - c;
       fill[o + i] = pre + incl - c;
+      if (c > kLongList) longs[1 + atomicAdd(&longs[0], 1)] = (int)(o + i);
     }
     __syncthreads();
     if (tid == 1023) carry = pre + incl;
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256) void chamfer_bwd_fill_kernel(const int *__rest
     const int na = second ? M : N;
     const int b = (int)(f / na);
     const int self = (int)(f - (long)b * na);
-    const int slot = second ? idx2[f] : N + idx1[f];
+    const int slot = second ? clamp_idx(idx2[f], N) : N + clamp_idx(idx1[f], M);
     const int pos = atomicAdd(&fill[(long)b * NM + slot], 1);
     list[(long)b * NM + pos] = self;
   }
@@ -283,7 +293,7 @@ constexpr int kBwdLdsSlots = 36864;
 __global__ __launch_bounds__(1024) void chamfer_bwd_lists_kernel(const int *__restrict__ idx1,
                                                                const int *__restrict__ idx2, int N, int M,
                                                                int *__restrict__ cnt, int *__restrict__ off,
-                                                               int *__restrict__ list) {
+                                                               int *__restrict__ list, int *__restrict__ longs) {
   extern __shared__ int lc[];  // N + M counters, later the fill cursors
   __shared__ int wsum[16];
   __shared__ int carry;
@@ -293,7 +303,7 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_lists_kernel(const int *__re
   for (int i = tid; i < NM; i += 1024) lc[i] = 0;
   if (tid == 0) carry = 0;
   __syncthreads();
-  for (int e = tid; e < NM; e += 1024) atomicAdd(&lc[e >= N ? i2[e - N] : N + i1[e]], 1);
+  for (int e = tid; e < NM; e += 1024) atomicAdd(&lc[e >= N ? clamp_idx(i2[e - N], N) : N + clamp_idx(i1[e], M)], 1);
   __syncthreads();
   for (int base = 0; base < NM; base += 1024) {
     const int i = base + tid;
@@ -311,6 +321,7 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_lists_kernel(const int *__re
       cnt[o + i] = c;
       off[o + i] = pre + incl - c;
       lc[i] = pre + incl - c;
+      if (c > kLongList) longs[1 + atomicAdd(&longs[0], 1)] = (int)(o + i);
     }
     __syncthreads();
     if (tid == 1023) carry = pre + incl;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(1024) void chamfer_bwd_lists_kernel(const int *__re
   }
   for (int e = tid; e < NM; e += 1024) {
     const bool second = e >= N;
-    const int pos = atomicAdd(&lc[second ? i2[e - N] : N + i1[e]], 1);
+    const int pos = atomicAdd(&lc[second ? clamp_idx(i2[e - N], N) : N + clamp_idx(i1[e], M)], 1);
     list[o + pos] = second ? e - N : e;
   }
 }
@@ -379,12 +390,13 @@ __global__ __launch_bounds__(256) void chamfer_bwd_gather_kernel(
     const float *gda = second ? gd2 : gd1, *gdo = second ? gd1 : gd2;
     const float *pa = a + f * 3;
     // own term: g (me - my neighbour)
-    const int k = (second ? idx2 : idx1)[f];
+    const int k = clamp_idx((second ? idx2 : idx1)[f], nb);
     const float *po = o + ((long)b * nb + k) * 3;
     const float g = gda[f] * 2;
     const float own[3] = {g * (pa[0] - po[0]), g * (pa[1] - po[1]), g * (pa[2] - po[2])};
     const long slot = (long)b * NM + (second ? N : 0) + self;
     const int c = cnt[slot];
+    if (c > kLongList) continue;  // chamfer_bwd_long_kernel's
     int *lst = list + (long)b * NM + off[slot];
     if (c > 1) sort_ints(lst, c);
     // cloud 1: own term first, then the scatter terms; cloud 2: scatter terms first, own term last
@@ -401,6 +413,90 @@ __global__ __launch_bounds__(256) void chamfer_bwd_gather_kernel(
     out[0] = second ? acc[0] + own[0] : acc[0];
     out[1] = second ? acc[1] + own[1] : acc[1];
     out[2] = second ? acc[2] + own[2] : acc[2];
+  }
+}
+
+// Long inverse lists: early in training (tanh outputs near 0) thousands of queries can share ONE nearest neighbour.
+// The gather above would let a single thread sort such a list in global memory and add its terms one dependent
+// load at a time (milliseconds for a 16384-entry list, where the reference's atomic scatter needs microseconds).
+// Here a workgroup takes the list: bitonic sort in LDS, then the terms in ascending order -- products computed 64 at
+// a time by a wave, the three running sums kept by three lanes (the order of the additions is the CPU path's, so
+// the result stays bit-equal to it).
+__global__ __launch_bounds__(256) void chamfer_bwd_long_kernel(
+    const float *__restrict__ xyz1, const float *__restrict__ xyz2, const float *__restrict__ gd1,
+    const float *__restrict__ gd2, const int *__restrict__ idx1, const int *__restrict__ idx2, int B, int N,
+    int M, const int *__restrict__ cnt, const int *__restrict__ off, int *__restrict__ list,
+    const int *__restrict__ longs, float *__restrict__ g1, float *__restrict__ g2) {
+#pragma clang fp contract(off)
+  extern __shared__ int keys[];  // kLongSortCap ints
+  __shared__ float terms[3][64];
+  const int tid = threadIdx.x, NM = N + M;
+  const int nlong = longs[0];
+  for (int li = blockIdx.x; li < nlong; li += gridDim.x) {
+    const long gslot = longs[1 + li];
+    const int b = (int)(gslot / NM), sl = (int)(gslot - (long)b * NM);
+    const bool second = sl >= N;
+    const int self = second ? sl - N : sl;
+    const int nb = second ? N : M;
+    const long f = (long)b * (second ? M : N) + self;
+    const float *a = second ? xyz2 : xyz1, *o = second ? xyz1 : xyz2;
+    const float *gda = second ? gd2 : gd1, *gdo = second ? gd1 : gd2;
+    const float *pa = a + f * 3;
+    const int c = cnt[gslot];
+    int *lst = list + (long)b * NM + off[gslot];
+    __syncthreads();  // the previous list's LDS keys are no longer needed
+    if (c <= kLongSortCap) {
+      int p2 = 1;
+      while (p2 < c) p2 <<= 1;
+      for (int i = tid; i < p2; i += 256) keys[i] = i < c ? lst[i] : 0x7fffffff;
+      __syncthreads();
+      for (int k = 2; k <= p2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          for (int i = tid; i < p2; i += 256) {
+            const int ixj = i ^ j;
+            if (ixj > i) {
+              const int x = keys[i], y = keys[ixj];
+              const bool up = (i & k) == 0;
+              if ((x > y) == up) {
+                keys[i] = y;
+                keys[ixj] = x;
+              }
+            }
+          }
+          __syncthreads();
+        }
+    } else {
+      if (tid == 0) sort_ints(lst, c);
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (tid < 64) {  // wave 0: ordered accumulation
+      const int k = clamp_idx((second ? idx2 : idx1)[f], nb);
+      const float *po = o + ((long)b * nb + k) * 3;
+      const float g = gda[f] * 2;
+      const float ax = tid < 3 ? pa[tid] : 0.f;
+      const float own = tid < 3 ? g * (ax - po[tid]) : 0.f;
+      float acc = second ? 0.f : own;   // lanes 0..2: x, y, z
+      for (int base = 0; base < c; base += 64) {
+        const int i = base + tid;
+        if (i < c) {
+          const long q = (long)b * nb + (c <= kLongSortCap ? keys[i] : lst[i]);
+          const float *pq = o + q * 3;
+          const float gq = gdo[q] * 2;
+          terms[0][tid] = gq * (pq[0] - pa[0]);
+          terms[1][tid] = gq * (pq[1] - pa[1]);
+          terms[2][tid] = gq * (pq[2] - pa[2]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int lim = c - base < 64 ? c - base : 64;
+        if (tid < 3)
+          for (int t = 0; t < lim; ++t) acc -= terms[tid][t];
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      if (tid < 3) (second ? g2 : g1)[f * 3 + tid] = second ? acc + own : acc;
+    }
   }
 }
 
@@ -424,7 +520,8 @@ extern "C" int sn_chamfer_forward(const float *xyz1, const float *xyz2, int b, i
 
 extern "C" size_t sn_chamfer_backward_workspace_bytes(int b, int n, int m) {
   if (b < 1 || n < 1 || m < 1) return 0;
-  return 4 * sn::align_up((size_t)b * ((size_t)n + m) * 4, 256);
+  const size_t arr = sn::align_up((size_t)b * ((size_t)n + m) * 4, 256);
+  return 4 * arr + sn::align_up(arr / 64 + 256, 256);  // cnt, off, fill, list + the directory of the long lists
 }
 
 extern "C" int sn_chamfer_backward(const float *xyz1, const float *xyz2, const float *graddist1,
@@ -445,23 +542,30 @@ extern "C" int sn_chamfer_backward(const float *xyz1, const float *xyz2, const f
   L.off = reinterpret_cast<int *>(p + arr);
   L.fill = reinterpret_cast<int *>(p + 2 * arr);
   L.list = reinterpret_cast<int *>(p + 3 * arr);
+  L.longs = reinterpret_cast<int *>(p + 4 * arr);
   const long total = (long)b * n + (long)b * m;
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = sn::as_stream(stream);
+  SN_HIP(hipMemsetAsync(L.longs, 0, 4, s));
   const size_t lds = ((size_t)n + m) * 4;
   if (n + m <= kBwdLdsSlots &&
       (lds <= 48 * 1024 ||  // per call: the attribute belongs to the current device
        hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_bwd_lists_kernel),
                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess)) {
-    chamfer_bwd_lists_kernel<<<b, 1024, lds, s>>>(idx1, idx2, n, m, L.cnt, L.off, L.list);
+    chamfer_bwd_lists_kernel<<<b, 1024, lds, s>>>(idx1, idx2, n, m, L.cnt, L.off, L.list, L.longs);
   } else {
     SN_HIP(hipMemsetAsync(L.cnt, 0, (size_t)b * ((size_t)n + m) * 4, s));
     chamfer_bwd_count_kernel<<<(int)blocks, 256, 0, s>>>(idx1, idx2, b, n, m, L.cnt);
-    chamfer_bwd_scan_kernel<<<b, 1024, 0, s>>>(n + m, L.cnt, L.off, L.fill);
+    chamfer_bwd_scan_kernel<<<b, 1024, 0, s>>>(n + m, L.cnt, L.off, L.fill, L.longs);
     chamfer_bwd_fill_kernel<<<(int)blocks, 256, 0, s>>>(idx1, idx2, b, n, m, L.fill, L.list);
   }
   chamfer_bwd_gather_kernel<<<(int)blocks, 256, 0, s>>>(xyz1, xyz2, graddist1, graddist2, idx1, idx2, b, n, m,
                                                         L.cnt, L.off, L.list, gradxyz1, gradxyz2);
+  // the lists beyond kLongList entries (none in a trained model: the kernel then reads one word and leaves)
+  SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(chamfer_bwd_long_kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, kLongSortCap * 4));
+  chamfer_bwd_long_kernel<<<128, 256, kLongSortCap * 4, s>>>(xyz1, xyz2, graddist1, graddist2, idx1, idx2, b, n, m,
+                                                            L.cnt, L.off, L.list, L.longs, gradxyz1, gradxyz2);
   return sn::launch_status("sn_chamfer_backward");
 }

@@ -220,17 +220,22 @@ def test_hip_full_size_properties(dev):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,n,m,kind", [(2, 3000, 1700, "uniform"), (1, 5000, 5000, "far"), (3, 513, 2049, "lattice"),
-                                        (1, 20000, 7, "uniform"), (1, 30000, 9000, "uniform")])
+                                        (1, 20000, 7, "uniform"), (1, 30000, 9000, "uniform"),
+                                        (2, 18000, 1, "uniform"), (2, 16384, 16384, "collapsed")])
 def test_hip_backward_bit_exact_incl_long_inverse_lists(b, n, m, kind, dev):
     """Backward against the oracle (= the reference CPU order), bit for bit.  "far": every query of one cloud
     shares ONE neighbour in the other (an inverse list of thousands of entries: the heap-sort path); the
     7-point cloud gives lists of ~3000 entries each; 30000 + 9000 points exceed the LDS counters of the
-    one-launch list builder (the three generic kernels run)."""
+    one-launch list builder (the three generic kernels run); a 1-point cloud gives one list of 18000 entries (beyond
+    the LDS sort of chamfer_bwd_long_kernel: the in-place fallback); "collapsed" is the early-training picture (every
+    prediction within 1e-3 of one point: a few targets collect thousands of queries each)."""
     rng = np.random.default_rng(n + m)
     x = rng.random((b, n, 3), dtype=np.float32)
     y = rng.random((b, m, 3), dtype=np.float32)
     if kind == "far":
         y = y * 0.01 + 40.0
+    if kind == "collapsed":
+        x = (0.5 + 1e-3 * (x - 0.5)).astype(np.float32)
     if kind == "lattice":
         x = (rng.integers(0, 5, (b, n, 3)) / 4).astype(np.float32)
         y = (rng.integers(0, 5, (b, m, 3)) / 4).astype(np.float32)
