@@ -560,13 +560,17 @@ __host__ __device__ inline TeamGeom team_geometry(int B, int W, int gmax = 64, i
     const int tpx = (B + 7) / 8;           // teams an XCD must host so that every cloud has its own
     int g = 1;
     while (g * 2 * tpx <= per && g * 2 <= gmax) g *= 2;
+    if (W < 128) g = 1;  // see below: concurrent launches on a small device
     t.G = g;
     t.teams = (per / g) * 8;
     t.xcd = 1;
   } else {
     int g = 1;
     while (g < 64 && g * 2 * B <= W && g * 2 <= gmax) g *= 2;
-    if (W < 128) g = 1;  // two concurrent launches may each hold up to G - 1 workgroups waiting: never on a small device
+    // Two launches on two streams can each hold the members of one incomplete team per ticket counter waiting for
+    // the rest (up to G - 1 compute units each): with fewer than 2 x 63 compute units that could be all of them, so
+    // small devices / partitions get teams of one workgroup, which wait for nobody.
+    if (W < 128) g = 1;
     t.G = g;
     t.teams = W / g > 0 ? W / g : 1;
     t.xcd = 0;

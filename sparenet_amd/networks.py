@@ -74,6 +74,26 @@ class SqueezeExcite(nn.Module):
         return x * gate.view(*gate.shape, *([1] * (x.dim() - 2)))
 
 
+class PrimitiveSqueezeExcite(nn.Module):
+    """One SqueezeExcite per primitive (the reference's GridDecoder carries its own se1..3,
+    models/sparenet_generator.py:1036-1040), evaluated for all P primitives at once: weights stacked [P, C/r, C] and
+    [P, C, C/r], input [B, P, C, n]."""
+
+    def __init__(self, primitives, channels, reduction=16):
+        super().__init__()
+        r = channels // reduction
+        self.w1 = nn.Parameter(torch.empty(primitives, r, channels))
+        self.w2 = nn.Parameter(torch.empty(primitives, channels, r))
+        for w, fan_in in ((self.w1, channels), (self.w2, r)):      # nn.Linear's default initialisation
+            if w.numel():                                           # channels < reduction: an empty bottleneck
+                nn.init.uniform_(w, -1.0 / math.sqrt(fan_in), 1.0 / math.sqrt(fan_in))
+
+    def forward(self, h):
+        z = F.relu(torch.einsum("bpc,prc->bpr", h.mean(dim=-1), self.w1.to(h.dtype)))
+        gate = torch.sigmoid(torch.einsum("bpr,pcr->bpc", z, self.w2.to(h.dtype)))
+        return h * gate.unsqueeze(-1)
+
+
 class EdgeConvEncoder(nn.Module):
     """partial cloud [B,3,M] -> style [B, bottleneck]: four EdgeConv stages (k-NN graph in FEATURE space on 3,
     h/16, h/16, h/8 channels; 1x1 conv on the [B,2C,M,k] edge features; BatchNorm; optional squeeze-excite;
@@ -157,16 +177,14 @@ class StyleFoldingDecoder(nn.Module):
             nn.init.uniform_(w, -bound, bound)
             nn.init.uniform_(b, -bound, bound)
         self.bn = nn.ModuleList(nn.BatchNorm1d(self.P * w) for w in self.widths)         # per primitive and channel
-        self.gate = nn.ModuleList(SqueezeExcite(w) if use_se else nn.Identity() for w in self.widths)
+        self.gate = nn.ModuleList(PrimitiveSqueezeExcite(self.P, w) if use_se else nn.Identity() for w in self.widths)
 
     def _post(self, h, layer, scale, shift):
         """AdaIN affine -> BatchNorm -> (gate) -> ReLU on [B,P,C,n]."""
         b, p, c, n = h.shape
         h = h * scale.view(b, 1, c, 1) + shift.view(b, 1, c, 1)
         h = self.bn[layer](h.reshape(b, p * c, n)).view(b, p, c, n)
-        if not isinstance(self.gate[layer], nn.Identity):
-            h = self.gate[layer](h.reshape(b * p, c, n)).view(b, p, c, n)
-        return F.relu(h)
+        return F.relu(self.gate[layer](h))
 
     def forward(self, style):
         b = style.shape[0]
@@ -259,6 +277,82 @@ class Generator(nn.Module):
         middle, loss_mst = self.refine(outs, part, coarse)
         refine, _ = self.refine(middle.transpose(1, 2).contiguous(), part, middle)
         return coarse, middle, refine, loss_mst
+
+
+def convert_reference_state_dict(ref_sd, n_primitives=None):
+    """The reference SpareNetGenerator's state_dict (encode="Residualnet", use_AdaIn="share";
+    models/sparenet_generator.py:12-82) re-keyed to `Generator`'s layout: EdgeConv stages as ModuleLists, the
+    per-primitive folding networks (and their squeeze-excite gates) STACKED along a leading primitive axis, their
+    BatchNorms concatenated.  Entries without a counterpart are dropped: the unused `conv1`, the unused
+    `refine.residual.bn7`, the AdaIN layers' running statistics (never read: AdaIN normalises per instance).
+    Accepts tensors or numpy arrays; returns a dict of tensors for `Generator.load_state_dict(..., strict=False)`
+    (use `load_reference_state_dict` to also verify that nothing is missing)."""
+    T = lambda v: v if isinstance(v, torch.Tensor) else torch.as_tensor(v)
+    sd = {k[7:] if k.startswith("module.") else k: T(v) for k, v in ref_sd.items()}   # DataParallel prefix
+    out = {}
+    fe = "encoder.feat_extractor."
+    stats = ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")
+
+    def norm(dst, src):
+        for s_ in stats:
+            if src + "." + s_ in sd:
+                out[dst + "." + s_] = sd[src + "." + s_]
+
+    for i in range(4):
+        out[f"encoder.edge.{i}.weight"] = sd[f"{fe}conv{i + 1}.weight"]
+        norm(f"encoder.norm.{i}", f"{fe}bn{i + 1}")
+        for fc in (0, 2):
+            if f"{fe}se{i + 1}.fc.{fc}.weight" in sd:
+                out[f"encoder.gate.{i}.fc.{fc}.weight"] = sd[f"{fe}se{i + 1}.fc.{fc}.weight"]
+    for i in range(3):
+        out[f"encoder.res.{i}.weight"] = sd[f"{fe}resconv{i + 1}.weight"]
+    out["encoder.head.weight"] = sd[f"{fe}conv5.weight"]
+    norm("encoder.head_norm", f"{fe}bn5")
+    out["encoder.linear.weight"], out["encoder.linear.bias"] = sd["encoder.linear.weight"], sd["encoder.linear.bias"]
+    norm("encoder.bn", "encoder.bn")
+    for k in ("mlp.0.weight", "mlp.0.bias", "mlp.2.weight", "mlp.2.bias"):
+        out["decoder." + k] = sd["decoder." + k]
+    P = n_primitives or 1 + max(int(k.split(".")[2]) for k in sd if k.startswith("decoder.decoder."))
+    prim = lambda p, k: sd[f"decoder.decoder.{p}.dec.{k}"]
+    for l in range(4):
+        out[f"decoder.weight.{l}"] = torch.stack([prim(p, f"conv{l + 1}.weight")[:, :, 0] for p in range(P)])
+        out[f"decoder.bias.{l}"] = torch.stack([prim(p, f"conv{l + 1}.bias") for p in range(P)])
+    for l in range(3):
+        for s_ in stats[:4]:
+            out[f"decoder.bn.{l}.{s_}"] = torch.cat([prim(p, f"bn{l + 1}.{s_}") for p in range(P)])
+        if f"decoder.decoder.0.dec.se{l + 1}.fc.0.weight" in sd:
+            out[f"decoder.gate.{l}.w1"] = torch.stack([prim(p, f"se{l + 1}.fc.0.weight") for p in range(P)])
+            out[f"decoder.gate.{l}.w2"] = torch.stack([prim(p, f"se{l + 1}.fc.2.weight") for p in range(P)])
+    rr = "refine.residual."
+    if rr + "conv1.weight" in sd:
+        for i in range(1, 7):
+            out[f"{rr}l{i}.0.weight"], out[f"{rr}l{i}.0.bias"] = sd[f"{rr}conv{i}.weight"], sd[f"{rr}conv{i}.bias"]
+            norm(f"{rr}l{i}.1", f"{rr}bn{i}")
+        out[rr + "out.weight"], out[rr + "out.bias"] = sd[rr + "conv7.weight"], sd[rr + "conv7.bias"]
+        for i in (1, 2, 4, 5, 6):
+            for fc in (0, 2):
+                if f"{rr}se{i}.fc.{fc}.weight" in sd:
+                    out[f"{rr}g{i}.fc.{fc}.weight"] = sd[f"{rr}se{i}.fc.{fc}.weight"]
+    return out
+
+
+def load_reference_state_dict(generator, ref_sd):
+    """Load a reference SpareNetGenerator checkpoint (its `state_dict()`, e.g. the `net_G` entry of a SpareNet
+    checkpoint file) into `generator`; raises if a parameter or buffer of `generator` is left without a value or a
+    shape does not fit.  Returns the reference keys that were not used."""
+    conv = convert_reference_state_dict(ref_sd, generator.decoder.P)
+    own = generator.state_dict()
+    missing = [k for k in own if k not in conv and "num_batches_tracked" not in k]
+    if missing:
+        raise KeyError(f"reference state_dict lacks what these entries need: {missing[:8]}{' ...' if len(missing) > 8 else ''}")
+    for k, v in conv.items():
+        if k not in own:
+            raise KeyError(f"converted entry {k} has no counterpart in the generator")
+        if tuple(own[k].shape) != tuple(v.shape):
+            raise ValueError(f"{k}: generator has {tuple(own[k].shape)}, reference gives {tuple(v.shape)}")
+    generator.load_state_dict(conv, strict=False)
+    used_prefixes = ("encoder.", "decoder.mlp", "decoder.decoder.", "refine.residual.")
+    return sorted(k for k in ref_sd if not k.startswith(used_prefixes) or ".adain" in k or "residual.bn7" in k)
 
 
 def _sn(module):

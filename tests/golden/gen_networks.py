@@ -114,13 +114,56 @@ def residual_case(ref, use_se, seed):
                 **{"p:" + k: v for k, v in sd.items()})
 
 
+def generator_case(ref, use_se, seed, with_residual):
+    """A reference-KEYED state_dict of a small generator (the reference's own SpareNetEncode / StyleBasedAdaIn /
+    PointNetRes instances under the key names SpareNetGenerator gives them -- SpareNetDecode itself hard-codes the
+    primitive width 1026, 1.3 M parameters per primitive, too large for a fixture) and the outputs of its three
+    parts in training mode: what sparenet_amd.networks.load_reference_state_dict has to reproduce."""
+    torch.manual_seed(seed)
+    P, n, hide, out, bott, width, B, M = 3, 32, 64, 64, 24, 32, 3, 40
+    # SpareNetEncode = EdgeConvResFeat + Linear + BatchNorm1d + ReLU (models/sparenet_generator.py:104-120); built
+    # from its parts because SpareNetEncode does not pass a small hide_size on to the feature extractor
+    feat = ref.EdgeConvResFeat(use_SElayer=use_se, k=8, output_size=out, hide_size=hide)
+    lin, bn = torch.nn.Linear(out, bott), torch.nn.BatchNorm1d(bott)
+    prims = [ref.StyleBasedAdaIn(input_dim=2, style_dim=bott, bottleneck_size=width, use_SElayer=use_se) for _ in range(P)]
+    mlp = torch.nn.Sequential(torch.nn.Linear(bott, bott), torch.nn.ReLU(),
+                              torch.nn.Linear(bott, ref.get_num_adain_params(prims[0])))
+    res = ref.PointNetRes(use_SElayer=use_se) if with_residual else None
+    x = torch.rand(B, 3, M) - 0.5
+    style = torch.relu(bn(lin(feat(x))))
+    grid = ref.grid_generation(P * n, P)
+    adain = mlp(style)
+    outs = []
+    for i in range(P):
+        g = torch.tensor(grid[i], dtype=torch.float32).transpose(0, 1).contiguous().unsqueeze(0)
+        g = ((g.expand(B, g.size(1), g.size(2)).contiguous() - 0.5) * 2).contiguous()
+        outs.append(prims[i](g, style, adain))
+    coarse = torch.cat(outs, 2)
+    base = torch.cat((coarse, torch.zeros(B, 1, P * n)), 1)
+    offs = res(base) if with_residual else torch.zeros(0)
+    sd = {"conv1.weight": torch.zeros(64, 3, 1), "conv1.bias": torch.zeros(64)}     # present in the reference, unused
+    sd.update({"encoder.feat_extractor." + k: v for k, v in feat.state_dict().items()})
+    sd.update({"encoder.linear." + k: v for k, v in lin.state_dict().items()})
+    sd.update({"encoder.bn." + k: v for k, v in bn.state_dict().items()})
+    sd.update({"decoder.mlp." + k: v for k, v in mlp.state_dict().items()})
+    for i, pr in enumerate(prims):
+        sd.update({f"decoder.decoder.{i}." + k: v for k, v in pr.state_dict().items()})
+    if with_residual:
+        sd.update({"refine.residual." + k: v for k, v in res.state_dict().items()})
+    return dict(kind="generator", use_se=use_se, P=P, n=n, hide=hide, out=out, bott=bott, width=width, x=x.numpy(),
+                style=style.detach().numpy(), coarse=coarse.detach().numpy(), offsets=offs.detach().numpy(),
+                **{"ref:" + k: v.detach().numpy() for k, v in sd.items()})
+
+
 def main():
     ref = reference_module()
     cases = {"networks_encoder": encoder_case(ref, False, 1), "networks_encoder_se": encoder_case(ref, True, 2),
-             "networks_decoder": decoder_case(ref, 3), "networks_residual": residual_case(ref, False, 4)}
+             "networks_decoder": decoder_case(ref, 3), "networks_residual": residual_case(ref, False, 4),
+             "networks_generator_sd": generator_case(ref, False, 5, False),
+             "networks_generator_sd_se": generator_case(ref, True, 6, True)}
     for name, c in cases.items():
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **c)
-        print(name, {k: getattr(v, "shape", v) for k, v in c.items() if not k.startswith("p:")})
+        print(name, {k: getattr(v, "shape", v) for k, v in c.items() if not k.startswith(("p:", "ref:"))})
 
 
 if __name__ == "__main__":

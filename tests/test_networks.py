@@ -317,3 +317,33 @@ def test_config5_full_size_gan_step(dev):
     assert any(not torch.equal(a, b) for a, b in zip(before_g, gen.parameters()))
     assert any(not torch.equal(a, b) for a, b in zip(before_d, disc.parameters()))
     print(f"config 5, 8 clouds on this rank: {min(times):.1f} ms per step (best of 2)")
+
+
+@pytest.mark.parametrize("name", ["networks_generator_sd", "networks_generator_sd_se"])
+def test_reference_checkpoint_loads_and_reproduces_the_reference(name, golden_dir):
+    """A state_dict under the REFERENCE's key names (encoder.feat_extractor.conv1 ..., decoder.decoder.<p>.dec.conv1
+    ..., refine.residual.conv1 ...; tests/golden/gen_networks.py builds it from the reference's own classes) loads
+    through networks.load_reference_state_dict, and the generator's parts then reproduce the reference's outputs --
+    including the per-primitive squeeze-excite gates of the decoder (use_SElayer: one SELayer1D per GridDecoder
+    layer and primitive, models/sparenet_generator.py:1036-1052)."""
+    z = np.load(os.path.join(golden_dir, name + ".npz"))
+    ref_sd = {k[4:]: z[k] for k in z.files if k.startswith("ref:")}
+    has_res = any(k.startswith("refine.") for k in ref_sd)
+    P, n = int(z["P"]), int(z["n"])
+    gen = nw.Generator(num_points=P * n, n_primitives=P, hide_size=int(z["hide"]), bottleneck_size=int(z["bott"]),
+                       width=int(z["width"]), use_se=bool(z["use_se"]), refine=has_res)
+    unused = nw.load_reference_state_dict(gen, ref_sd)
+    assert "conv1.weight" in unused and all(("adain" in k or "bn7" in k or k.startswith("conv1.")) for k in unused)
+    gen.train()
+    style = gen.encoder(torch.from_numpy(z["x"]))
+    np.testing.assert_allclose(style.detach().numpy(), z["style"], rtol=2e-4, atol=2e-5)
+    coarse = gen.decoder(torch.from_numpy(z["style"]))
+    np.testing.assert_allclose(coarse.detach().numpy(), z["coarse"], rtol=2e-4, atol=2e-5)
+    if has_res:
+        base = torch.cat((torch.from_numpy(z["coarse"]), torch.zeros(coarse.shape[0], 1, coarse.shape[2])), 1)
+        offs = gen.refine.residual(base)
+        np.testing.assert_allclose(offs.detach().numpy(), z["offsets"], rtol=2e-4, atol=2e-5)
+    # a checkpoint that lacks something the generator needs is refused, not half-loaded
+    broken = {k: v for k, v in ref_sd.items() if k != "decoder.mlp.2.bias"}
+    with pytest.raises(KeyError):
+        nw.load_reference_state_dict(gen, broken)
