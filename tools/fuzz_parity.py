@@ -42,10 +42,10 @@ kinds = ["uniform", "lattice", "clustered", "surface", "line", "far", "dup"]
 t_end = time.time() + budget
 runs = fails = 0
 while time.time() < t_end:
-    # mostly small batches (teams that span XCDs); one run in three a batch of 32+ clouds: XCD-local teams whose
-    # stores stay in their L2, teams of 4 / 2 workgroups, teams that serve several clouds in turn
+    # mostly small batches (one XCD = 32 workgroups per cloud up to 8 clouds, then teams of 16); one run in three a
+    # batch of 32+ clouds: teams of 8 / 4 / 2 workgroups, teams that serve several clouds in turn
     big = rng.random() < 0.33
-    b = int(rng.choice([32, 33, 48, 64, 70])) if big else int(rng.integers(1, 6))
+    b = int(rng.choice([32, 33, 48, 64, 70])) if big else int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 12, 16, 17]))
     n = int(rng.choice([1024, 2048])) if big else int(rng.choice([1024, 2048, 3072, 4096]))
     k1, k2 = rng.choice(kinds), rng.choice(kinds)
     x, y = cloud(b, n, k1), cloud(b, n, k2)
