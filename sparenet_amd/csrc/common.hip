@@ -99,6 +99,39 @@ int check_sticky(int dev, const char *what) {
   return 0;
 }
 
+namespace {
+struct Chain {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  bool recorded = false;
+};
+Chain g_chain[64];
+}  // namespace
+
+PersistentLaunch::PersistentLaunch(int dev, hipStream_t stream) : dev_(dev), stream_(stream), chained_(false) {
+  if (dev_ < 0 || dev_ >= 64) return;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream_, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return;
+  }
+  Chain &c = g_chain[dev_];
+  c.mu.lock();
+  chained_ = true;
+  if (!c.ev && hipEventCreateWithFlags(&c.ev, hipEventDisableTiming) != hipSuccess) {
+    c.ev = nullptr;
+    (void)hipGetLastError();
+  }
+  if (c.ev && c.recorded) (void)hipStreamWaitEvent(stream_, c.ev, 0);
+}
+
+PersistentLaunch::~PersistentLaunch() {
+  if (!chained_) return;
+  Chain &c = g_chain[dev_];
+  if (c.ev && hipEventRecord(c.ev, stream_) == hipSuccess) c.recorded = true;
+  c.mu.unlock();
+}
+
 void clear_sticky(int dev) {
   if (dev < 0 || dev >= 64) return;
   std::lock_guard<std::mutex> lk(g_sticky_mu);

@@ -56,6 +56,29 @@ unsigned *sticky_device_word(int dev);            // nullptr if the word could n
 int check_sticky(int dev, const char *what);      // 0, or SN_ETIMEDOUT (clears the word, fills sn_last_error)
 void clear_sticky(int dev);
 
+// Launches whose workgroups WAIT for each other (the persistent EMD auction, the sampler's dense-regime teams) must
+// not overlap each other on a device: each may hold compute units with members of a not-yet-complete team, and two
+// such launches on two streams could hold all of them between them -- neither team ever completes, both give up
+// after their spin limit.  (Ordinary kernels on other streams are harmless: they finish and free their CUs.)
+// PersistentLaunch orders them on the GPU without a host synchronisation: the constructor makes `stream` wait for
+// the event of the previous such launch of this process on the device, the destructor records the event behind the
+// new launch; a host mutex is held in between, so launches from several host threads chain one after the other.
+// Skipped while `stream` is being captured into a graph (an event recorded outside the capture cannot be waited
+// for inside it); launches of OTHER processes sharing the GPU are beyond its reach -- for those the bounded waits
+// and the sticky error word remain.
+class PersistentLaunch {
+ public:
+  PersistentLaunch(int dev, hipStream_t stream);
+  ~PersistentLaunch();
+  PersistentLaunch(const PersistentLaunch &) = delete;
+  PersistentLaunch &operator=(const PersistentLaunch &) = delete;
+
+ private:
+  int dev_;
+  hipStream_t stream_;
+  bool chained_;
+};
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

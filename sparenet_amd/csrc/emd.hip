@@ -522,8 +522,10 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
 //   * The unassigned count of the next iteration (the reference's tie geometry needs it) is accumulated
 //     with one atomic per wave while Assign raises the flags.
 //   * Teams are formed from a TICKET taken at start, not from blockIdx: a workgroup only ever waits for
-//     workgroups that have started, and at most one block of teams per launch is incomplete at any time,
-//     so concurrent launches on other streams cannot starve each other (each can hold <= 63 CUs waiting).
+//     workgroups that have started, and at most one team per ticket counter is incomplete at any time, so ordinary
+//     kernels on other streams only delay a launch (they finish and free their CUs).  Two TEAM-WAITING launches of
+//     this process never overlap: sn::PersistentLaunch chains them through an event (common.hpp) -- between them
+//     they could otherwise hold every CU of an XCD with members of incomplete teams.
 //     With >= 32 clouds a team is G consecutive tickets of ONE XCD's counter (the XCD read from the hardware
 //     register: its L2 then keeps the cloud's streams; speed only); fewer clouds get larger, contiguous
 //     teams from one global counter.
@@ -1686,7 +1688,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
-    SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, 0, s>>>(args)));
+    {
+      sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
+      SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, 0, s>>>(args)));
+    }
     if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;
       SN_HIP(hipStreamSynchronize(s));

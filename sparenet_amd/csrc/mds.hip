@@ -914,6 +914,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
         unsigned *sticky = sn::sticky_device_word(dev);
         SN_REQUIRE(team_slots * team_g <= 1024, "sn_mds: unexpected team geometry");
         SN_HIP(hipMemsetAsync(tctl, 0, 128 + 128 * 3 * (size_t)team_slots * team_g, s));
+        sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
 #define SN_MDST(P)                                                                                          \
   {                                                                                                         \
     SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_dense_team_kernel<P>),                   \

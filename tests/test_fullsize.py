@@ -379,3 +379,40 @@ def test_emd_self_test_passes_and_safe_mode_is_bit_exact(dev):
         assert np.array_equal(a.cpu().numpy(), ab) and np.array_equal(d.cpu().numpy(), db)
     finally:
         del os.environ["SN_EMD_SAFE"]
+
+
+@pytest.mark.gpu
+def test_team_waiting_launches_on_several_streams_complete_and_agree(dev):
+    """Two auctions and a dense-regime sampling issued back to back on THREE streams, small batches (teams of 32 / 16
+    workgroups: each launch on its own could hold most of an XCD's compute units with members of an incomplete
+    team).  The library chains such launches through an event (sn::PersistentLaunch), so they run one after the
+    other on the GPU without a host synchronisation: all finish promptly (far below the 2 s spin limit) with the
+    oracle's results."""
+    import time
+    from sparenet_amd.cuda.emd.emd_module import emd_forward_raw
+    from sparenet_amd.cuda.MDS.MDS_module import minimum_density_sample
+
+    g = torch.Generator().manual_seed(77)
+    x1, y1 = torch.rand(4, 4096, 3, generator=g), torch.rand(4, 4096, 3, generator=g)
+    x2, y2 = torch.rand(2, 8192, 3, generator=g), torch.rand(2, 8192, 3, generator=g)
+    xm = torch.rand(3, 19384, 3, generator=g)
+    mm = torch.full((3,), 0.09)
+    want1 = oracle.emd_forward(x1.numpy(), y1.numpy(), 0.005, 30, mt=True)
+    want2 = oracle.emd_forward(x2.numpy(), y2.numpy(), 0.005, 30, mt=True)
+    wantm = oracle.mds(xm.numpy(), 1500, mm.numpy(), exp_mode=1)
+    t = [v.to(dev) for v in (x1, y1, x2, y2, xm, mm)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    torch.cuda.synchronize()
+    for rep in range(3):
+        t0 = time.perf_counter()
+        with torch.cuda.stream(streams[0]):
+            d1, a1 = emd_forward_raw(t[0], t[1], 0.005, 30)
+        with torch.cuda.stream(streams[1]):
+            im = minimum_density_sample(t[4], 1500, t[5])
+        with torch.cuda.stream(streams[2]):
+            d2, a2 = emd_forward_raw(t[2], t[3], 0.005, 30)
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 1.0
+        assert np.array_equal(a1.cpu().numpy(), want1[1]) and np.array_equal(d1.cpu().numpy(), want1[0])
+        assert np.array_equal(a2.cpu().numpy(), want2[1]) and np.array_equal(d2.cpu().numpy(), want2[0])
+        assert np.array_equal(im.cpu().numpy(), wantm)
