@@ -19,8 +19,9 @@ Scaling (whole clouds are independent, ranks own contiguous slices, n
   `other_scaling`, so one driver run per N yields both curves.
   `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run,
   one process per GPU, RCCL); under a launcher (WORLD_SIZE set) it is one of the ranks.
-The four parts are independent given the predicted cloud; by default the renderer runs on a second
-HIP stream next to the distance losses (config.streams = 2; --no-overlap times the one-stream step).
+The four parts are independent given the predicted cloud; by default the renderer runs on a second HIP
+stream and the expansion penalty on a third next to Chamfer + EMD (config.streams = 3; --no-overlap times the
+one-stream step).
 After the timed region the same steps run once more one stream at a time, untimed for `value`, to
 report per-part times and the kernels' uncontended durations (roofline.isolated).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
@@ -161,6 +162,8 @@ class HotPath:
         self.stats = torch.zeros(2, dtype=torch.int64, device=dev)
         self.last_mean_mst = None
         self.side = None
+        self.side2 = None
+        self.three_streams = os.environ.get("BENCH_THREE_STREAMS", "1") == "1"   # 0: round 2's two-stream step (A/B)
 
     def _emd(self, pred, gt):
         """emdFunction with the effective-pair counter attached."""
@@ -200,10 +203,12 @@ class HotPath:
         return acc
 
     def step_overlapped(self, pred, gt):
-        """The same step with the renderer on a second HIP stream: the four parts are independent given the
-        predicted cloud; the renderer overlaps the expansion penalty, Chamfer and the auction's preparation (the
-        persistent auction itself owns every CU it runs on).  Same kernels, same results; per-kernel durations
-        stretch under contention.  (Measured and not kept, r03: at <= 8 clouds per rank the auction's XCD-local
+        """The same step on three HIP streams: the four parts are independent given the predicted cloud.  Main:
+        Chamfer, then the auction; second: the renderer; third: the expansion penalty (lone waves for ~0.45 ms:
+        beside Chamfer it costs nothing, in front of it -- round 2 -- it cost its full length: 5.46 -> 5.36 ms at 32
+        clouds, 2.25 -> 2.02 at 4).  The renderer overlaps Chamfer, the expansion penalty and the auction's
+        preparation; the persistent auction itself owns every CU it runs on.  Same kernels, same results; per-kernel
+        durations stretch under contention.  (Measured and not kept, r03: at <= 8 clouds per rank the auction's XCD-local
         teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
         SLOWER whichever side was enqueued first: 2.52-2.54 vs 2.26 ms at 4 clouds, 2.86 vs 2.54 at 8.)"""
         main = torch.cuda.current_stream()
@@ -216,7 +221,21 @@ class HotPath:
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
         acc.record_stream(main)
-        loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt)
+        if self.three_streams:
+            # the expansion penalty is one lone wave per 512-point patch for ~0.45 ms (latency bound, the SIMDs nearly
+            # idle): on a third stream it runs BESIDE Chamfer instead of in front of it
+            if self.side2 is None:
+                self.side2 = torch.cuda.Stream()
+            pred.record_stream(self.side2)
+            self.side2.wait_stream(main)
+            with torch.cuda.stream(self.side2):
+                loss_exp = self._loss_expansion(pred)
+            loss_exp.record_stream(main)
+            loss_cd = self._loss_cd(pred, gt)
+            loss_emd = self._loss_emd(pred, gt)
+            main.wait_stream(self.side2)
+        else:
+            loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt)
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
         return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
@@ -816,7 +835,8 @@ def main():
                              f"{radius_list} px -> 256x256 fwd+bwd; scalar-loss all-reduce"),
                 "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
                 "emd_iters": EMD_ITERS, "radius_list": radius_list,
-                "image": IMG, "views": N_VIEWS, "streams": 2 if overlap else 1, "library_build": build_id,
+                "image": IMG, "views": N_VIEWS,
+                "streams": (3 if hp.three_streams else 2) if overlap else 1, "library_build": build_id,
                 "render": "view by view" if args.per_view_render else "8 views in one pass (forward_views)",
             },
             "other_scaling": other,
