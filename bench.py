@@ -20,8 +20,8 @@ Scaling (whole clouds are independent, ranks own contiguous slices, n
   `python bench.py --gpus N` with N > 1 and no launcher around it starts the N ranks itself (torch.distributed.run,
   one process per GPU, RCCL); under a launcher (WORLD_SIZE set) it is one of the ranks.
 The four parts are independent given the predicted cloud; by default the renderer runs on a second HIP
-stream and the expansion penalty on a third next to Chamfer + EMD (config.streams = 3; --no-overlap times the
-one-stream step).
+stream next to the distance losses, and at <= 16 clouds per rank the expansion penalty on a third
+(config.streams = 2 / 3; --no-overlap times the one-stream step).
 After the timed region the same steps run once more one stream at a time, untimed for `value`, to
 report per-part times and the kernels' uncontended durations (roofline.isolated).
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line:
@@ -163,7 +163,7 @@ class HotPath:
         self.last_mean_mst = None
         self.side = None
         self.side2 = None
-        self.three_streams = os.environ.get("BENCH_THREE_STREAMS", "1") == "1"   # 0: round 2's two-stream step (A/B)
+        self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: by batch
 
     def _emd(self, pred, gt):
         """emdFunction with the effective-pair counter attached."""
@@ -203,10 +203,9 @@ class HotPath:
         return acc
 
     def step_overlapped(self, pred, gt):
-        """The same step on three HIP streams: the four parts are independent given the predicted cloud.  Main:
-        Chamfer, then the auction; second: the renderer; third: the expansion penalty (lone waves for ~0.45 ms:
-        beside Chamfer it costs nothing, in front of it -- round 2 -- it cost its full length: 5.46 -> 5.36 ms at 32
-        clouds, 2.25 -> 2.02 at 4).  The renderer overlaps Chamfer, the expansion penalty and the auction's
+        """The same step on two or three HIP streams: the four parts are independent given the predicted cloud.  Main:
+        (expansion penalty,) Chamfer, then the auction; second: the renderer; third, at <= 16 clouds per rank: the
+        expansion penalty (see three_streams).  The renderer overlaps Chamfer, the expansion penalty and the auction's
         preparation; the persistent auction itself owns every CU it runs on.  Same kernels, same results; per-kernel
         durations stretch under contention.  (Measured and not kept, r03: at <= 8 clouds per rank the auction's XCD-local
         teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
@@ -221,7 +220,7 @@ class HotPath:
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
         acc.record_stream(main)
-        if self.three_streams:
+        if self.three_streams(pred.size(0)):
             # the expansion penalty is one lone wave per 512-point patch for ~0.45 ms (latency bound, the SIMDs nearly
             # idle): on a third stream it runs BESIDE Chamfer instead of in front of it
             if self.side2 is None:
@@ -239,6 +238,17 @@ class HotPath:
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
         return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
+
+    def three_streams(self, clouds):
+        """Third stream for the expansion penalty?  At <= 16 clouds per rank (the strong-scaling shares) it takes the
+        penalty's 0.36-0.40 ms off the critical path: 3.44 -> 3.34, 2.52 -> 2.36, 2.25 -> 1.98 ms per step at 16 / 8 /
+        4 clouds.  At 32 clouds the step gains 2 % (5.52 -> 5.40 ms) but the persistent auction then waits ~0.3 ms
+        for compute units that the 1024 lone waves -- slower beside renderer and Chamfer -- still occupy, which
+        stretches its LIVE launch duration (2.83 ms against 2.52 uncontended and in the rocprofv3 summary): there the
+        two-stream step is kept, so that the roofline's live duration stays the kernel's."""
+        if self.three_streams_env in ("0", "1"):
+            return self.three_streams_env == "1"
+        return clouds <= 16
 
     def _loss_expansion(self, pred):
         # one wave per 512-point patch = lone waves for 0.35-0.45 ms, latency bound: next to another stream's work
@@ -836,7 +846,7 @@ def main():
                 "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
                 "emd_iters": EMD_ITERS, "radius_list": radius_list,
                 "image": IMG, "views": N_VIEWS,
-                "streams": (3 if hp.three_streams else 2) if overlap else 1, "library_build": build_id,
+                "streams": (3 if hp.three_streams(b_local) else 2) if overlap else 1, "library_build": build_id,
                 "render": "view by view" if args.per_view_render else "8 views in one pass (forward_views)",
             },
             "other_scaling": other,
