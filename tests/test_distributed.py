@@ -99,3 +99,49 @@ def test_sharded_step_equals_unsharded_on_the_product_path(dev):
     maps_part = render((pred - 0.5)[lo:hi].contiguous(), view_id=1, radius_list=[5.0])
     assert not torch.equal(maps_whole[lo:hi], maps_part)          # local z-range normalisation
     assert (maps_whole[lo:hi] > 0).eq(maps_part > 0).all()        # same footprints, different depth scale
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` (N > 1, no launcher around it) re-executes itself under torch.distributed.run with
+    one process per GPU on 127.0.0.1 (the reference spreads a batch over its GPUs from one command too,
+    runners/base_runner.py:100-104), and refuses to run fewer ranks than asked."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2"])
+    args = bench.parse()
+    assert args.gpus == 8 and args.scaling == "strong"          # auto = the strong split of SURVEY 8(e)
+    monkeypatch.delenv("BENCH_DEBUG_SHARED_GPU", raising=False)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert "only 1 GPU(s) visible" in str(e.value) and "cmd" not in seen
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    with pytest.raises(SystemExit) as e:
+        bench.launch_ranks(args)
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "5", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"     # dmabuf IPC: RCCL needs it on this driver
+
+
+def test_bench_step_schedule_by_batch():
+    """Third stream for the expansion penalty only at <= 16 clouds per rank (bench.HotPath.three_streams)."""
+    import bench
+
+    hp = bench.HotPath.__new__(bench.HotPath)
+    hp.three_streams_env = None
+    assert [hp.three_streams(b) for b in (32, 16, 8, 4)] == [False, True, True, True]
+    hp.three_streams_env = "0"
+    assert not hp.three_streams(4)
