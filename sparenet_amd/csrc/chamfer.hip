@@ -547,6 +547,7 @@ extern "C" int sn_chamfer_backward(const float *xyz1, const float *xyz2, const f
   long blocks = (total + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipStream_t s = sn::as_stream(stream);
+  SN_REFUSE_CAPTURE(s, "sn_chamfer_backward");
   SN_HIP(hipMemsetAsync(L.longs, 0, 4, s));
   const size_t lds = ((size_t)n + m) * 4;
   if (n + m <= kBwdLdsSlots &&

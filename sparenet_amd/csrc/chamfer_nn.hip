@@ -352,6 +352,7 @@ extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, i
              "sn_chamfer_forward_sorted: workspace too small (%zu < %zu)", workspace_bytes,
              sn_chamfer_workspace_bytes(b, n, m));
   hipStream_t s = sn::as_stream(stream);
+  SN_REFUSE_CAPTURE(s, "sn_chamfer_forward_sorted");
   char *p = static_cast<char *>(workspace);
   NnSide s1 = carve_side(p, xyz1, b, n), s2 = carve_side(p, xyz2, b, m);
   int *cell_of = reinterpret_cast<int *>(p);  // sort scratch, shared by the two clouds

@@ -79,6 +79,22 @@ class PersistentLaunch {
   bool chained_;
 };
 
+// true while `stream` is being captured into a HIP graph
+inline bool capturing(hipStream_t s) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool yes = hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if (!yes) (void)hipGetLastError();
+  return yes;
+}
+
+// Ops that were found NOT to replay correctly from a HIP graph on ROCm 7.2 / gfx950 (tools/graph_probe.py: the
+// persistent auction's replay runs into its barrier time-outs, the Chamfer kernels' replay dies with a memory access
+// fault although the same launches are clean in eager mode with every input at the end of its allocation,
+// tools/oob_probe.py) refuse to be captured instead of producing a graph that misbehaves later.
+#define SN_REFUSE_CAPTURE(stream, what)                                                                     \
+  SN_REQUIRE(!sn::capturing(stream), what ": the stream is being captured into a HIP graph; this op does not " \
+                                           "replay correctly from a graph (see common.hpp) -- launch it eagerly")
+
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1627,6 +1627,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
              "sn_emd_forward: workspace too small (%zu < %zu)", workspace_bytes,
              sn_emd_workspace_bytes(b, n));
   hipStream_t s = sn::as_stream(stream);
+  SN_REFUSE_CAPTURE(s, "sn_emd_forward");
   int dev = 0, cus = 0;
   SN_HIP(hipGetDevice(&dev));
   SN_REQUIRE(dev >= 0 && dev < 64, "sn_emd_forward: unexpected device ordinal %d", dev);

@@ -909,6 +909,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
         team_g = g;
         team_slots = 8 * tpx;
       }
+      if (team_g >= 2 && sn::capturing(s)) team_g = 1;  // under graph capture: the one-workgroup kernel only
       if (team_g >= 2) {
         const int pg = (ppt + team_g - 1) / team_g;
         unsigned *sticky = sn::sticky_device_word(dev);
