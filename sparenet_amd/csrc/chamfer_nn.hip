@@ -337,7 +337,7 @@ NnSide carve_side(char *&p, const float *xyz, int b, int n) {
 extern "C" size_t sn_chamfer_workspace_bytes(int b, int n, int m) {
   if (b < 1 || n < 1 || m < 1) return 0;
   const int big = n > m ? n : m;
-  return side_bytes(b, n).total + side_bytes(b, m).total + sn::align_up((size_t)b * big * 4, 256);
+  return side_bytes(b, n).total + side_bytes(b, m).total + 2 * sn::align_up((size_t)b * big * 4, 256);
 }
 
 extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, int b, int n, int m,
@@ -355,11 +355,13 @@ extern "C" int sn_chamfer_forward_sorted(const float *xyz1, const float *xyz2, i
   SN_REFUSE_CAPTURE(s, "sn_chamfer_forward_sorted");
   char *p = static_cast<char *>(workspace);
   NnSide s1 = carve_side(p, xyz1, b, n), s2 = carve_side(p, xyz2, b, m);
-  int *cell_of = reinterpret_cast<int *>(p);  // sort scratch, shared by the two clouds
+  int *cell_of = reinterpret_cast<int *>(p);  // sort scratch of cloud 1; cloud 2's follows it
+  int *cell_of2 = reinterpret_cast<int *>(p + sn::align_up((size_t)b * (n > m ? n : m) * 4, 256));
   if (sn::prof_enabled()) sn::prof_begin("chamfer_fwd", s);
+  SN_REQUIRE(cloud_sort_pair(b, SortSide{s1.n, s1.xyz, s1.bbox, s1.hist, cell_of, s1.perm},
+                             SortSide{s2.n, s2.xyz, s2.bbox, s2.hist, cell_of2, s2.perm}, s) == 0,
+             "sn_chamfer_forward_sorted: cannot size the sort kernel's LDS");
   for (NnSide *side : {&s1, &s2}) {
-    SN_REQUIRE(cloud_sort(b, side->n, side->xyz, side->bbox, side->hist, cell_of, side->perm, s) == 0,
-               "sn_chamfer_forward_sorted: cannot size the sort kernel's LDS");
     const long sbs = (long)b * side->nsb;
     nn_prepare_kernel<<<(int)((sbs + 3) / 4 < 4096 ? (sbs + 3) / 4 : 4096), 256, 0, s>>>(b, *side);
   }

@@ -1654,9 +1654,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   const EmdWs ws = carve(workspace, b, n);
   const long total = (long)b * n;
   const int eblocks = (int)((total + kThreads - 1) / kThreads < 2048 ? (total + kThreads - 1) / kThreads : 2048);
-  SN_REQUIRE(cloud_sort(b, n, xyz2, ws.bbox, ws.hist, ws.cell_of, ws.tperm, s) == 0,
-             "sn_emd_forward: cannot size the sort kernel's LDS");
-  SN_REQUIRE(cloud_sort(b, n, xyz1, ws.bbox1, ws.hist1, ws.cell_of, ws.perm1, s) == 0,
+  // both clouds' Hilbert sorts in one launch; the bidders' cell ids go to `flags` for the moment (every word of it
+  // is written by emd_init_kernel afterwards)
+  SN_REQUIRE(cloud_sort_pair(b, SortSide{n, xyz2, ws.bbox, ws.hist, ws.cell_of, ws.tperm},
+                             SortSide{n, xyz1, ws.bbox1, ws.hist1, ws.flags, ws.perm1}, s) == 0,
              "sn_emd_forward: cannot size the sort kernel's LDS");
   static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
