@@ -987,6 +987,261 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
 #endif
 }
 
+// ---------------------------------------------------------------------------------------
+// Bid phase of a SPARSE iteration: one quarter wave (16 lanes) per bidder.
+//
+// Once a workgroup has at most kScanMax unassigned bidders they are ~1 / 32 of their rank range apart: a group
+// of 16 of them spans a third of the cloud, the union of their reaches (what bid_group's waves visit with the
+// matrix cores) is several times what any ONE of them can reach, and an iteration is a chain of dependent steps
+// (box tests -> ~9 visits -> hit queue -> merge of 16 segments) whose length, not whose work, sets the time.
+// Here every bidder is served on its own: its reach (from the two previous favourites, exactly bid_group's bound)
+// is tested against the boxes of the groups of 16 superblocks and then of the superblocks (both in LDS: two box
+// tests per lane and one per group within reach), and the targets of the superblocks within reach are read
+// directly -- lane c takes targets c, 16 + c, 32 + c, 48 + c of the 64, eight loads in flight per superblock
+// pair -- through the precise filter; what passes waits in two register slots per lane and takes the reference's
+// arithmetic at the end; the 16 lanes' top-2's meet through four DPP steps.  No matrix cores, no queue, no LDS
+// election, no merge across waves, no __syncthreads: four round trips of set-up, one for the candidates.
+// The same three facts make it exact: a target outside the reach cannot pass the precise filter, a target that
+// fails the precise filter has a value below a proven lower bound of the bidder's final `better`, and top2_push /
+// top2_merge give the full scan's values and canonical index in any order.
+// ---------------------------------------------------------------------------------------
+#ifndef SN_EMD_SCAN_MAX
+#define SN_EMD_SCAN_MAX 256 // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides)
+#endif
+constexpr int kScanBlk = 1024;  // blocks of 16 targets whose boxes fit in the LDS copy (n <= 16384)
+constexpr int kScanList = 64;   // blocks within reach a quarter wave lists before it evaluates them
+
+struct ScanLds {
+  f4 hb[kScanBlk / 16][2];  // boxes of the groups of 16 blocks (256 targets), laid out like a row of sbbox
+  f4 blk[kScanBlk][2];      // the cloud's sbbox rows
+  unsigned short list[kBidWaves][4][kScanList];
+};
+
+__device__ __forceinline__ bool box_within(const f4 A, const f4 B, float x, float y, float z, float r2) {
+  const float gx = __builtin_fmaxf(__builtin_fmaxf(A.x - x, x - A.w), 0.f);
+  const float gy = __builtin_fmaxf(__builtin_fmaxf(A.y - y, y - B.x), 0.f);
+  const float gz = __builtin_fmaxf(__builtin_fmaxf(A.z - z, z - B.y), 0.f);
+  return ((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2;
+}
+
+#define SN_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
+#define SN_DPP_I(v, ctrl) __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true)
+
+constexpr int kRoundC = 4;  // blocks per round (two rounds are in flight: the register budget decides)
+struct ScanCand {  // one round of a quarter wave: lane c holds target c of each of the round's blocks
+  f4 t[kRoundC];     // {x, y, z, index bits}
+  float p[kRoundC];  // today's price
+};
+
+
+__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int wave,
+                                         int lane) {
+  const int row = lane >> 4, col = lane & 15;
+  const int nh = c.nsb >> 2;  // groups of 16 blocks
+  const TieGeom geom = c.geom;
+  const f4 *t4 = c.t4;
+  const float2 *pkc = c.pkc;
+  unsigned short *lq = SL.list[wave][row];
+#undef STAMP
+#undef COUNT
+#ifdef SN_BID_STAMPS
+  long long st[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long tk = (long long)__builtin_amdgcn_s_memrealtime();
+#define STAMP(i) { const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); st[i] += now_ - tk; tk = now_; }
+#define COUNT(i, v) st[i] += (v);
+#else
+#define STAMP(i)
+#define COUNT(i, v)
+#endif
+  for (int u0 = 0; u0 < count;) {
+    // T quarter waves per bidder: with few bidders left a bidder's superblocks are dealt out to 2 or 4 quarters
+    const int rem = count - u0;
+    const int tsh = rem <= 16 ? 2 : (rem <= 32 ? 1 : 0), T = 1 << tsh;  // uniform in the workgroup
+    const int qd = wave * 4 + row;
+    const int u = u0 + (qd >> tsh), part = qd & (T - 1);
+    const bool active = u < count;  // uniform within the quarter
+    int jj = 0, rank = 0, ba = -1, bb = -1;  // ba, bb: the blocks of the two previous favourites
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f, cm = -1e9f, r2 = -3.0e38f;
+    if (active) {
+      const int2 jr = ldc2(&lst[2 * u]);  // {bidder index, Morton rank}
+      jj = jr.x;
+      rank = jr.y;
+      x1 = c.p1[jj * 3 + 0];
+      y1 = c.p1[jj * 3 + 1];
+      z1 = c.p1[jj * 3 + 2];
+      const int pa = ldc(&c.A.bid[c.o + jj]), pb = ldc(&c.A.bid2[c.o + jj]);
+      if (pa >= 0 && pb >= 0) {
+        const int qa = c.rk2[pa], qb = c.rk2[pb];
+        const f4 ta = t4[qa], tb = t4[qb];
+        const float da = bid_value(ta.x, ta.y, ta.z, ldc_pk(pkc + qa).x, x1, y1, z1);
+        const float db = bid_value(tb.x, tb.y, tb.z, ldc_pk(pkc + qb).x, x1, y1, z1);
+        cm = __builtin_fminf(da, db);
+        ba = qa >> 4;
+        bb = qb >> 4;
+      }
+      {
+#pragma clang fp contract(off)
+        const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
+        const float v = coarse_threshold(cm, 2.f * 3.814697265625e-06f * (c.tmax + xx), c.a_max);
+        r2 = v > 0.f ? v * 1.0001f : v;
+      }
+    }
+    Top2 top = {-1e9f, -1e9f, -1, -1};
+    float qlb = -1e9f;  // the team's second-best value after its first round (see below)
+    bool first = true;
+    STAMP(0)
+    // groups of 16 blocks within reach: lane c tests groups c, 16 + c, 32 + c, 48 + c
+    unsigned long long hm = 0;
+    for (int h0 = 0; h0 < nh; h0 += 16) {
+      const int h = h0 + col < nh ? h0 + col : 0;
+      const bool w = h0 + col < nh && box_within(SL.hb[h][0], SL.hb[h][1], x1, y1, z1, r2);
+      hm |= ((__ballot(w) >> (16 * row)) & 0xffffull) << h0;
+    }
+    auto fetch = [&](ScanCand &B, int i, int cnt) {
+#pragma unroll
+      for (int q = 0; q < kRoundC; ++q) {
+        const int pos = 16 * (i + q < cnt ? (int)lq[i + q] : 0) + col;
+        B.t[q] = t4[pos];
+        B.p[q] = ldc(reinterpret_cast<const float *>(pkc + pos));
+      }
+    };
+    auto process = [&](const ScanCand &B, int i, int cnt) {
+      COUNT(6, 1)
+      const float lb = __builtin_fmaxf(top.better, qlb);
+      const float cthr = filter_thr(__builtin_fmaxf(cm, lb));
+      float sqv[kRoundC];
+      unsigned mask = 0;
+#pragma unroll
+      for (int e = 0; e < kRoundC; ++e) {
+        sqv[e] = sq_dist(B.t[e].x, B.t[e].y, B.t[e].z, x1, y1, z1);
+        const bool pass = i + e < cnt && filter_pass(sqv[e], filter_target(B.p[e]), cthr);
+        mask |= pass ? 1u << e : 0u;
+      }
+      while (__any(mask != 0u)) {  // what passes (rare) takes the reference's arithmetic, one candidate per lane and turn
+        COUNT(12, __popcll(__ballot(mask != 0u)))
+        COUNT(13, 1)
+        if (mask != 0u) {
+          const int e = __builtin_ctz(mask);
+          mask &= mask - 1u;
+          float sq = sqv[0], pr = B.p[0], kf = B.t[0].w;
+#pragma unroll
+          for (int q = 1; q < kRoundC; ++q) {
+            sq = e == q ? sqv[q] : sq;
+            pr = e == q ? B.p[q] : pr;
+            kf = e == q ? B.t[q].w : kf;
+          }
+          const float d = (float)((3.0 - (double)__builtin_sqrtf(sq)) - (double)pr);
+          top2_push(top, d, __float_as_int(kf), geom);
+        }
+      }
+    };
+    do {
+      // The blocks within reach into the lists of the team's quarters, dealt out in turn.  The blocks of the two
+      // previous favourites go first: after the round that holds them the team knows two values near the final
+      // top two, shares the second one once (`qlb`), and hardly anything passes the filter afterwards.
+      int all = 0, cnt = 0;
+      if (first && ba >= 0) {
+        if (part == 0) lq[0] = (unsigned short)ba;
+        all = 1;
+        if (bb != ba) {
+          if ((1 & (T - 1)) == part) lq[1 >> tsh] = (unsigned short)bb;
+          all = 2;
+        }
+        cnt = (all + T - 1 - part) >> tsh;
+      }
+      while (__any(hm != 0ull && cnt <= kScanList - 32)) {  // two groups per turn: their box reads overlap
+        if (hm != 0ull && cnt <= kScanList - 32) {           // uniform within the quarter
+          const int h0 = __builtin_ctzll(hm);
+          hm &= hm - 1ull;
+          const bool two = hm != 0ull;
+          const int h1 = two ? __builtin_ctzll(hm) : h0;
+          hm = two ? hm & (hm - 1ull) : hm;
+          const int s0 = 16 * h0 + col, s1 = 16 * h1 + col;
+          const f4 a0 = SL.blk[s0][0], c0 = SL.blk[s0][1], a1 = SL.blk[s1][0], c1 = SL.blk[s1][1];
+          const bool w0 = s0 != ba && s0 != bb && box_within(a0, c0, x1, y1, z1, r2);
+          const bool w1 = two && s1 != ba && s1 != bb && box_within(a1, c1, x1, y1, z1, r2);
+          const unsigned b0 = (unsigned)((__ballot(w0) >> (16 * row)) & 0xffffull);
+          const unsigned b1 = (unsigned)((__ballot(w1) >> (16 * row)) & 0xffffull);
+          const unsigned below = (1u << col) - 1u;
+          const int p0 = all + __popc(b0 & below);
+          if (w0 && (p0 & (T - 1)) == part) lq[p0 >> tsh] = (unsigned short)s0;
+          all += __popc(b0);
+          const int p1 = all + __popc(b1 & below);
+          if (w1 && (p1 & (T - 1)) == part) lq[p1 >> tsh] = (unsigned short)s1;
+          all += __popc(b1);
+          cnt = (all + T - 1 - part) >> tsh;
+        }
+      }
+      asm volatile("" ::: "memory");
+      STAMP(1)
+      COUNT(8, __builtin_amdgcn_readfirstlane(cnt))
+      // their targets, round by round, the next round's loads in flight during a round
+      if (__any(cnt > 0)) {
+        ScanCand A, B;
+        fetch(A, 0, cnt);
+        for (int i = 0;;) {
+          const bool more = __any(i + kRoundC < cnt);
+          if (more) fetch(B, i + kRoundC, cnt);
+          process(A, i, cnt);
+          if (first) {  // uniform: the first round of the bidder
+            first = false;
+            float m1 = top.best, m2 = top.better;
+#define SN_SHARE_STEP(o1_, o2_)                                                  \
+            {                                                                    \
+              const float o1 = o1_, o2 = o2_;                                    \
+              m2 = __builtin_fmaxf(__builtin_fminf(m1, o1), __builtin_fmaxf(m2, o2)); \
+              m1 = __builtin_fmaxf(m1, o1);                                      \
+            }
+            SN_SHARE_STEP(SN_DPP_F(m1, 0xB1), SN_DPP_F(m2, 0xB1))
+            SN_SHARE_STEP(SN_DPP_F(m1, 0x4E), SN_DPP_F(m2, 0x4E))
+            SN_SHARE_STEP(SN_DPP_F(m1, 0x141), SN_DPP_F(m2, 0x141))
+            SN_SHARE_STEP(SN_DPP_F(m1, 0x140), SN_DPP_F(m2, 0x140))
+            for (int d = 16; d < 16 * T; d <<= 1) SN_SHARE_STEP(__shfl_xor(m1, d), __shfl_xor(m2, d))
+#undef SN_SHARE_STEP
+            qlb = m2;  // lanes and quarters hold disjoint targets: the second largest value seen bounds the final `better`
+          }
+          i += kRoundC;
+          if (!more) break;
+          const bool more2 = __any(i + kRoundC < cnt);
+          if (more2) fetch(A, i + kRoundC, cnt);
+          process(B, i, cnt);
+          i += kRoundC;
+          if (!more2) break;
+        }
+      }
+      first = false;
+      asm volatile("" ::: "memory");
+      STAMP(2)
+    } while (__any(hm != 0ull));
+    // the quarter's 16 partial results: xor 1, xor 2, mirror within 8, mirror within 16; then the team's quarters
+#define SN_TOP2_STEP(ctrl)                                                                              \
+    {                                                                                                   \
+      const float ob = SN_DPP_F(top.best, ctrl), obb = SN_DPP_F(top.better, ctrl);                      \
+      const int oi = SN_DPP_I(top.best_i, ctrl), oi2 = SN_DPP_I(top.better_i, ctrl);                    \
+      top2_merge(top, ob, obb, oi, oi2, geom);                                                          \
+    }
+    SN_TOP2_STEP(0xB1)
+    SN_TOP2_STEP(0x4E)
+    SN_TOP2_STEP(0x141)
+    SN_TOP2_STEP(0x140)
+#undef SN_TOP2_STEP
+    for (int d = 16; d < 16 * T; d <<= 1) {  // uniform
+      const float ob = __shfl_xor(top.best, d), obb = __shfl_xor(top.better, d);
+      const int oi = __shfl_xor(top.best_i, d), oi2 = __shfl_xor(top.better_i, d);
+      top2_merge(top, ob, obb, oi, oi2, geom);
+    }
+    if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, c.stash, top, c.eps);
+    STAMP(4)
+    u0 += 64 >> tsh;
+  }
+#ifdef SN_BID_STAMPS
+  if (c.stamps && lane == 0)
+    for (int i = 0; i < 16; ++i) c.stamps[i] += st[i];
+#endif
+#undef STAMP
+#undef COUNT
+}
+
 struct AuctionArgs {
   int B, n, iters;
   float eps;
@@ -1006,14 +1261,41 @@ struct AuctionArgs {
              // (sn_emd_diag_offset), zeroed by the call.  Bit 2 (4): every team a mixed-XCD one; bit 3 (8): the
              // second workgroup of team 0 leaves at once and barriers give up early (tests the time-out path).
   long long *dwords;
+  int scan_max;  // iterations with at most this many bidders in the workgroup take bid_scan (0: never)
 };
 
-__global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(AuctionArgs a) {
-  __shared__ WaveTab tabs[kBidWaves];
-  __shared__ GroupAcc gacc[kBidWaves];
-  __shared__ BidStash stash[kStash];
-  __shared__ int wsum[kBidWaves];
-  __shared__ int s_flag, s_ticket, s_stray, s_range[3], s_bins[kRankBins];
+// The kernel's LDS, carved from the DYNAMIC segment on purpose: with a static 101 KB the compiler derives "one
+// workgroup per CU = 4 waves per SIMD" from the LDS size and hands every wave 128 VGPRs whatever the occupancy
+// attributes say, which leaves no register for anybody else on the CU.  With SN_EMD_OCC waves per SIMD asked for
+// (5 -> 96 VGPRs) a quarter of every SIMD's register file stays free, and workgroups of OTHER launches (the
+// renderer's gather: 52 VGPRs, no LDS) run beside the auction in the issue slots its waves leave idle while they
+// wait (wait_frac 0.66).
+struct AuctionLds {
+  WaveTab tabs[kBidWaves];
+  GroupAcc gacc[kBidWaves];
+  BidStash stash[kStash];
+  int wsum[kBidWaves];
+  int s_flag, s_ticket, s_stray, s_range[3], s_bins[kRankBins];
+  ScanLds scan;
+};
+
+#ifndef SN_EMD_OCC
+#define SN_EMD_OCC 4
+#endif
+
+__global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
+                          amdgpu_waves_per_eu(SN_EMD_OCC, SN_EMD_OCC))) void emd_auction_kernel(AuctionArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char auction_lds[];
+  AuctionLds &L = *reinterpret_cast<AuctionLds *>(auction_lds);
+  WaveTab *tabs = L.tabs;
+  GroupAcc *gacc = L.gacc;
+  BidStash *stash = L.stash;
+  int *wsum = L.wsum;
+  int &s_flag = L.s_flag, &s_ticket = L.s_ticket, &s_stray = L.s_stray;
+  int *s_range = L.s_range, *s_bins = L.s_bins;
+#ifdef SN_EMD_PRIO
+  __builtin_amdgcn_s_setprio(SN_EMD_PRIO);  // the chain of dependent steps goes first; co-resident waves fill the gaps
+#endif
   const int tid = threadIdx.x;
   if (tid < kBidWaves) {
     gacc[tid].lock = 0;
@@ -1126,6 +1408,32 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
     c.A = bo;
     c.stash = stash;
     const int *perm1 = a.ws.perm1 + o;
+    // bid_scan's copy of the cloud's box hierarchy (constant for the whole call)
+    const bool scan_ok = a.scan_max > 0 && 4 * nsb <= kScanBlk;  // nsb % 16 == 0 (n % 1024 == 0)
+    if (scan_ok) {
+      __syncthreads();  // a team that serves several clouds: nobody still reads the previous cloud's boxes
+      {
+        const f4 *src = reinterpret_cast<const f4 *>(c.sbb);  // [n / 16] rows {lo x, lo y, lo z, hi x}, {hi y, hi z, -, -}
+        f4 *dst = &L.scan.blk[0][0];
+        for (int i = tid; i < 8 * nsb; i += kBidThreads) dst[i] = src[i];
+      }
+      __syncthreads();
+      for (int h = tid; h < (nsb >> 2); h += kBidThreads) {
+        f4 lo = L.scan.blk[16 * h][0], hi = L.scan.blk[16 * h][1];
+        for (int q = 1; q < 16; ++q) {
+          const f4 l2 = L.scan.blk[16 * h + q][0], h2 = L.scan.blk[16 * h + q][1];
+          lo.x = __builtin_fminf(lo.x, l2.x);
+          lo.y = __builtin_fminf(lo.y, l2.y);
+          lo.z = __builtin_fminf(lo.z, l2.z);
+          lo.w = __builtin_fmaxf(lo.w, l2.w);
+          hi.x = __builtin_fmaxf(hi.x, h2.x);
+          hi.y = __builtin_fmaxf(hi.y, h2.y);
+        }
+        L.scan.hb[h][0] = lo;
+        L.scan.hb[h][1] = hi;
+      }
+      __syncthreads();
+    }
 
     for (int it = 0; it < a.iters; ++it) {
       const int cur = it & 1;
@@ -1233,17 +1541,21 @@ __global__ __launch_bounds__(kBidThreads, SN_EMD_WAVES) void emd_auction_kernel(
         c.prt = (a.eps >= 0.f && it > 0 && U * 16 <= n) ? reinterpret_cast<const f4 *>(a.ws.prt + o) : nullptr;
         const float price_floor = a.eps < 0.f ? a.eps * (float)it : 0.f;
         c.a_max = filter_target(price_floor) + 9.5367431640625e-07f;
-        const int ngroups = (Um + 63) >> 6;
-        int S = 1;
-        while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
-        const int gpb = kBidWaves / S;
-        const int seg = wave & (S - 1), gslot = wave / S;
 #ifdef SN_BID_STAMPS
         c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
 #endif
-        for (int q0 = 0; q0 < ngroups; q0 += gpb) {
-          bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
-          if (q0 + gpb < ngroups) __syncthreads();
+        if (scan_ok && Um <= a.scan_max) {  // sparse iteration (uniform in the workgroup): a quarter wave per bidder
+          bid_scan(c, L.scan, llist, Um, wave, lane);
+        } else {
+          const int ngroups = (Um + 63) >> 6;
+          int S = 1;
+          while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
+          const int gpb = kBidWaves / S;
+          const int seg = wave & (S - 1), gslot = wave / S;
+          for (int q0 = 0; q0 < ngroups; q0 += gpb) {
+            bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
+            if (q0 + gpb < ngroups) __syncthreads();
+          }
         }
       }
       if (a.diag) __syncthreads();
@@ -1683,6 +1995,11 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     static const int diag = [] { const char *e = getenv("SN_EMD_DIAG"); return e ? atoi(e) : 0; }();
     static const int gmax = [] { const char *e = getenv("SN_EMD_G"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
     static const int legacy = [] { const char *e = getenv("SN_EMD_GEOM"); return e && e[0] == '1' ? 1 : 0; }();
+    {  // read per call: the tests compare the two bid paths inside one process
+      const char *e = getenv("SN_EMD_SCAN");
+      const int v = e ? atoi(e) : SN_EMD_SCAN_MAX;
+      args.scan_max = v < 0 ? 0 : v;
+    }
     args.tg = team_geometry(b, cus * kWgPerCu, gmax, legacy);
     args.diag = diag;
     args.spin_limit = (diag & 8) ? (1u << 15) : kSpinLimit;
@@ -1691,8 +2008,16 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
     {
+      static std::once_flag lds_once[64];  // 101 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced
+      hipError_t lds_rc = hipSuccess;
+      std::call_once(lds_once[dev & 63], [&] {
+        lds_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_auction_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
+      });
+      SN_REQUIRE(lds_rc == hipSuccess, "sn_emd_forward: hipFuncSetAttribute(%zu bytes of LDS): %s", sizeof(AuctionLds),
+                 hipGetErrorString(lds_rc));
       sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
-      SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, 0, s>>>(args)));
+      SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, sizeof(AuctionLds), s>>>(args)));
     }
     if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;

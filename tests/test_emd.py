@@ -142,6 +142,27 @@ def test_hip_matches_oracle(b, n, iters, eps, kind, seed, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("scan", ["0", "48", "1000000"])
+def test_hip_both_bid_paths_match_oracle(scan, dev, monkeypatch):
+    """The bid phase has two forms: the matrix-core search of a group of 64 bidders (dense iterations) and the
+    per-bidder scan by quarter waves (iterations with at most SN_EMD_SCAN bidders per workgroup, default 256).
+    SN_EMD_SCAN is read per call: 0 = group search only, 48 = a switch late in the call (and the 2 / 4 quarters per
+    bidder forms of the scan), 10^6 = the scan from the first iteration on (several passes of 64 bidders, no previous
+    favourites for a start).  Ties, negative eps, clusters, far offsets, a size whose boxes do not fit the LDS copy."""
+    monkeypatch.setenv("SN_EMD_SCAN", scan)
+    for b, n, iters, eps, kind, seed in [(2, 1024, 15, 0.005, "near", 4), (2, 1024, 6, 0.005, "lattice", 5),
+                                         (1, 3072, 4, 0.01, "lattice", 6), (2, 2048, 10, -0.001, "uniform", 10),
+                                         (1, 8192, 6, 0.005, "clustered", 11), (2, 1024, 8, 0.005, "far", 12),
+                                         (9, 1024, 20, 0.005, "uniform", 9), (1, 16384, 9, 0.005, "uniform", 13),
+                                         (1, 32768, 3, 0.005, "uniform", 14)]:
+        x, y = _clouds(b, n, seed, kind)
+        d0, a0 = oracle.emd_forward(x, y, eps, iters, mt=True)
+        d1, a1 = _hip(x, y, eps, iters, dev)
+        assert np.array_equal(a0, a1), (scan, b, n, iters, kind)
+        assert np.array_equal(d0, d1), (scan, b, n, iters, kind)
+
+
+@pytest.mark.gpu
 def test_hip_prices_bit_exact_when_converged(dev):
     """Sensitive arithmetic check: when the auction converges before the last
     iteration (no forced assignment, hence no price race), the price vector --
