@@ -1149,8 +1149,9 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
         }
         cnt = (all + T - 1 - part) >> tsh;
       }
-      while (__any(hm != 0ull && cnt <= kScanList - 32)) {  // two groups per turn: their box reads overlap
-        if (hm != 0ull && cnt <= kScanList - 32) {           // uniform within the quarter
+      // (the quarters of a team must stop at the same group: the test is on `all`, which they share, not on `cnt`)
+      while (__any(hm != 0ull && ((all + T - 1) >> tsh) <= kScanList - 32)) {  // two groups per turn: their box reads overlap
+        if (hm != 0ull && ((all + T - 1) >> tsh) <= kScanList - 32) {           // uniform within the TEAM
           const int h0 = __builtin_ctzll(hm);
           hm &= hm - 1ull;
           const bool two = hm != 0ull;
