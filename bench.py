@@ -244,9 +244,11 @@ class HotPath:
         return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
 
     def _step_auction_first(self, pred, gt, main):
-        """The auction on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two
-        more streams beside it.  The auction's workgroups take 96 of a SIMD's 128 VGPRs per wave slot quarter and wait
-        two thirds of their cycles; the other launches' waves fit in the registers it leaves free."""
+        """A/B only (BENCH_ORDER=auction_first; measured and not made the default): the auction
+        on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two more streams
+        beside it.  With a library built with -DSN_EMD_OCC=5 the auction's waves hold 96 VGPRs each, and the other
+        launches' waves fit on the same CUs in the registers it leaves free: the step gains 5 % at 32 clouds while
+        the auction's own launch stretches from 2.6 to 4.5 ms (and the step loses at <= 16 clouds)."""
         if self.hi is None:
             self.hi = torch.cuda.Stream(priority=-1)
             self.side = self.side or torch.cuda.Stream()
@@ -257,14 +259,9 @@ class HotPath:
         with torch.cuda.stream(self.hi):
             loss_emd = self._loss_emd(pred, gt)
         loss_emd.record_stream(main)
-        delay = int(os.environ.get("BENCH_RENDER_DELAY", "0"))   # experiment: let the auction become resident first
         with torch.cuda.stream(self.side):
-            if delay:
-                torch.cuda._sleep(delay)
             acc = self._render_all(pred)
         acc.record_stream(main)
-        if delay:
-            torch.cuda._sleep(delay)
         loss_exp = self._loss_expansion(pred)
         loss_cd = self._loss_cd(pred, gt)
         main.wait_stream(self.hi)

@@ -634,6 +634,8 @@ struct BidCtx {
   TieGeom geom;
   size_t o;
   const float *p1;   // bidders of this cloud
+  const float *p2;   // targets of this cloud by INDEX (the caller's array)
+  const float *price;  // prices by target index (coherent reads)
   const f4 *t4;      // by stream position; prices inside change between the phases (no __restrict__)
   const float2 *pkc;
   const int *rk2;
@@ -990,23 +992,33 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
 // ---------------------------------------------------------------------------------------
 // Bid phase of a SPARSE iteration: one quarter wave (16 lanes) per bidder.
 //
-// Once a workgroup has at most kScanMax unassigned bidders they are ~1 / 32 of their rank range apart: a group
-// of 16 of them spans a third of the cloud, the union of their reaches (what bid_group's waves visit with the
+// Once a workgroup has at most SN_EMD_SCAN_MAX unassigned bidders they are far apart in their rank range: a
+// group of 16 of them spans a third of the cloud, the union of their reaches (what bid_group's waves visit with the
 // matrix cores) is several times what any ONE of them can reach, and an iteration is a chain of dependent steps
 // (box tests -> ~9 visits -> hit queue -> merge of 16 segments) whose length, not whose work, sets the time.
-// Here every bidder is served on its own: its reach (from the two previous favourites, exactly bid_group's bound)
-// is tested against the boxes of the groups of 16 superblocks and then of the superblocks (both in LDS: two box
-// tests per lane and one per group within reach), and the targets of the superblocks within reach are read
-// directly -- lane c takes targets c, 16 + c, 32 + c, 48 + c of the 64, eight loads in flight per superblock
-// pair -- through the precise filter; what passes waits in two register slots per lane and takes the reference's
-// arithmetic at the end; the 16 lanes' top-2's meet through four DPP steps.  No matrix cores, no queue, no LDS
-// election, no merge across waves, no __syncthreads: four round trips of set-up, one for the candidates.
+// Here every bidder is served on its own:
+//  * set-up, two round trips: the list entry waits in LDS (left in the slot's stash by the compaction), the two
+//    previous favourites' coordinates and prices are read BY INDEX (the caller's array, the award phase's price
+//    array); their values give bid_group's bound `cm` and the reach r2 (the same formulas);
+//  * the reach against the boxes of the groups of 16 blocks (256 targets), then of the blocks of 16 targets of
+//    the groups within reach -- all in LDS (ScanLds: the cloud's sbbox rows, copied once per cloud), four box
+//    tests per lane and one per group within reach; the blocks within reach go to a list in LDS, the blocks of
+//    the two previous favourites first;
+//  * the listed blocks' targets, four blocks per round, lane c = target c of each: coordinates + price of the
+//    next round are in flight while a round goes through the precise filter; what passes (~7 targets per bidder)
+//    takes the reference's arithmetic at once; after the FIRST round (which holds the favourites' blocks) the
+//    lanes share the second largest value they have seen, a bound that is final in most cases;
+//  * the 16 lanes' top-2's meet through four DPP steps.
+// With few bidders left 2 or 4 quarter waves share a bidder (its blocks dealt out in turn), so that a workgroup
+// with 16 bidders -- the 4-clouds-per-GPU share of an 8-GPU job -- still uses all of its lanes.
+// No matrix cores, no queue, no LDS election, no merge across waves, no __syncthreads.
 // The same three facts make it exact: a target outside the reach cannot pass the precise filter, a target that
-// fails the precise filter has a value below a proven lower bound of the bidder's final `better`, and top2_push /
-// top2_merge give the full scan's values and canonical index in any order.
+// fails the precise filter has a value below a proven lower bound of the bidder's final `better` (a stale or
+// smaller bound only lets more through), and top2_push / top2_merge give the full scan's values and canonical
+// index in any order.
 // ---------------------------------------------------------------------------------------
 #ifndef SN_EMD_SCAN_MAX
-#define SN_EMD_SCAN_MAX 256 // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides)
+#define SN_EMD_SCAN_MAX 256  // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides)
 #endif
 constexpr int kScanBlk = 1024;  // blocks of 16 targets whose boxes fit in the LDS copy (n <= 16384)
 constexpr int kScanList = 64;   // blocks within reach a quarter wave lists before it evaluates them
@@ -1038,6 +1050,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
                                          int lane) {
   const int row = lane >> 4, col = lane & 15;
   const int nh = c.nsb >> 2;  // groups of 16 blocks
+  const int nblk = c.nsb << 2;
   const TieGeom geom = c.geom;
   const f4 *t4 = c.t4;
   const float2 *pkc = c.pkc;
@@ -1063,21 +1076,28 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
     int jj = 0, rank = 0, ba = -1, bb = -1;  // ba, bb: the blocks of the two previous favourites
     float x1 = 0.f, y1 = 0.f, z1 = 0.f, cm = -1e9f, r2 = -3.0e38f;
     if (active) {
-      const int2 jr = ldc2(&lst[2 * u]);  // {bidder index, Morton rank}
-      jj = jr.x;
-      rank = jr.y;
+      // two round trips: {coordinates, previous favourites} of the bidder, then the favourites' coordinates and
+      // prices BY INDEX (the caller's array and the price array of the award phase; their stream positions, needed
+      // for the lists only, arrive beside them)
+      if (u < kStash) {  // left there by the compaction
+        jj = c.stash[u].tgt;
+        rank = c.stash[u].rank;
+      } else {
+        const int2 jr = ldc2(&lst[2 * u]);  // {bidder index, Morton rank}
+        jj = jr.x;
+        rank = jr.y;
+      }
       x1 = c.p1[jj * 3 + 0];
       y1 = c.p1[jj * 3 + 1];
       z1 = c.p1[jj * 3 + 2];
       const int pa = ldc(&c.A.bid[c.o + jj]), pb = ldc(&c.A.bid2[c.o + jj]);
       if (pa >= 0 && pb >= 0) {
-        const int qa = c.rk2[pa], qb = c.rk2[pb];
-        const f4 ta = t4[qa], tb = t4[qb];
-        const float da = bid_value(ta.x, ta.y, ta.z, ldc_pk(pkc + qa).x, x1, y1, z1);
-        const float db = bid_value(tb.x, tb.y, tb.z, ldc_pk(pkc + qb).x, x1, y1, z1);
+        const float *ta = c.p2 + pa * 3, *tb = c.p2 + pb * 3;
+        const float da = bid_value(ta[0], ta[1], ta[2], ldc(&c.price[pa]), x1, y1, z1);
+        const float db = bid_value(tb[0], tb[1], tb[2], ldc(&c.price[pb]), x1, y1, z1);
         cm = __builtin_fminf(da, db);
-        ba = qa >> 4;
-        bb = qb >> 4;
+        ba = c.rk2[pa] >> 4;
+        bb = c.rk2[pb] >> 4;
       }
       {
 #pragma clang fp contract(off)
@@ -1092,15 +1112,20 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
     STAMP(0)
     // groups of 16 blocks within reach: lane c tests groups c, 16 + c, 32 + c, 48 + c
     unsigned long long hm = 0;
-    for (int h0 = 0; h0 < nh; h0 += 16) {
+#pragma unroll
+    for (int h0 = 0; h0 < kScanBlk / 16; h0 += 16) {  // nh <= 64: the four turns' box reads go out together
       const int h = h0 + col < nh ? h0 + col : 0;
       const bool w = h0 + col < nh && box_within(SL.hb[h][0], SL.hb[h][1], x1, y1, z1, r2);
       hm |= ((__ballot(w) >> (16 * row)) & 0xffffull) << h0;
     }
     auto fetch = [&](ScanCand &B, int i, int cnt) {
+      // the round's four list entries in ONE 8-byte LDS read; entries past the quarter's count are stale or
+      // uninitialised words: clamped to a block of this cloud, loaded, and ignored by process()
+      const uint2 e4 = *reinterpret_cast<const uint2 *>(lq + i);
+      const unsigned id[4] = {e4.x & 0xffffu, e4.x >> 16, e4.y & 0xffffu, e4.y >> 16};
 #pragma unroll
       for (int q = 0; q < kRoundC; ++q) {
-        const int pos = 16 * (i + q < cnt ? (int)lq[i + q] : 0) + col;
+        const int pos = 16 * (int)(id[q] < (unsigned)nblk ? id[q] : 0u) + col;
         B.t[q] = t4[pos];
         B.p[q] = ldc(reinterpret_cast<const float *>(pkc + pos));
       }
@@ -1401,6 +1426,8 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
     c.tmax = tmax;
     c.o = o;
     c.p1 = a.xyz1 + o * 3;
+    c.p2 = a.xyz2 + o * 3;
+    c.price = a.ws.price + o;
     c.t4 = a.ws.t4s + o;
     c.pkc = a.ws.pk + o;
     c.rk2 = a.ws.rank2 + o;
@@ -1522,10 +1549,19 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
           }
           if (cnt > 0) {
             const int r = r0 + 4 * w;
-            if (f.x) { stc2(loc, &llist[2 * pos], perm1[r], r); ++pos; }
-            if (f.y) { stc2(loc, &llist[2 * pos], perm1[r + 1], r + 1); ++pos; }
-            if (f.z) { stc2(loc, &llist[2 * pos], perm1[r + 2], r + 2); ++pos; }
-            if (f.w) { stc2(loc, &llist[2 * pos], perm1[r + 3], r + 3); ++pos; }
+            // the list entry also waits in the slot's (still unused) stash for bid_scan: one round trip less
+            auto put = [&](int j, int rr) {
+              stc2(loc, &llist[2 * pos], j, rr);
+              if (pos < kStash) {
+                stash[pos].tgt = j;
+                stash[pos].rank = rr;
+              }
+              ++pos;
+            };
+            if (f.x) put(perm1[r], r);
+            if (f.y) put(perm1[r + 1], r + 1);
+            if (f.z) put(perm1[r + 2], r + 2);
+            if (f.w) put(perm1[r + 3], r + 3);
           }
           base += total;
           __syncthreads();
