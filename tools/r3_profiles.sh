@@ -29,6 +29,8 @@ echo "== emd phases + per batch size"
 SN_EMD_DIAG=2 AB_BS=32 AB_DIAG_B=32 timeout 600 python tools/emd_ab.py 2>&1 | grep -v amdgpu > $O/emd_phases_b32.txt; tail -2 $O/emd_phases_b32.txt | cut -c1-250
 SN_EMD_DIAG=2 AB_BS=4 AB_DIAG_B=4 timeout 600 python tools/emd_ab.py 2>&1 | grep -v amdgpu > $O/emd_phases_b4.txt; tail -2 $O/emd_phases_b4.txt | cut -c1-250
 AB_BS=32,16,8,4,2,1 timeout 600 python tools/emd_ab.py 2>&1 | grep "ms per call" | tee $O/emd_per_batch.txt
+SN_EMD_SCAN=0 AB_BS=32,16,8,4,2,1 timeout 600 python tools/emd_ab.py 2>&1 | grep "ms per call" | sed 's/^/SN_EMD_SCAN=0 (group search in every iteration): /' | tee -a $O/emd_per_batch.txt
+SN_EMD_SCAN=0 SN_EMD_DIAG=2 AB_BS=32 AB_DIAG_B=32 timeout 600 python tools/emd_ab.py 2>&1 | grep -v amdgpu > $O/emd_phases_b32_group_search_only.txt; tail -1 $O/emd_phases_b32_group_search_only.txt | cut -c1-250
 echo "== strong share"; timeout 600 python tools/strong_share.py 2>&1 | grep -v amdgpu | tee $O/strong_share.txt
 echo "== mds teams"; timeout 600 python tools/mds_ab.py 2>&1 | grep -v amdgpu | tee $O/mds_teams.txt; SN_MDS_G=1 timeout 600 python tools/mds_ab.py 2>&1 | grep -v amdgpu | sed 's/^/teams off: /' | tee -a $O/mds_teams.txt
 echo "== render kernels"; (python tools/render_probe.py; KTOP=12 tools/kstats.sh tools/render_probe.py) 2>&1 | grep -v "amdgpu\|^E2026" | tee $O/render_kernels.txt | tail -12
