@@ -809,7 +809,11 @@ def main():
                 "note": ("`achieved` / `frac` = executed work (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 + SQ_INSTS_VALU x 64 "
                          "per launch, every vector instruction counted as 64 useful lanes) / live launch time / fp32 "
                          "peak (vector = f32 MFMA dense peak); null when no counters of this build are committed. "
-                         "The kernel is latency bound (wait_frac), not pipe or HBM bound."),
+                         "One plain vector instruction per SIMD every 4 cycles is 39 T lane-operations/s = 0.25 by "
+                         "this measure: a kernel whose work is unpacked vector instructions reaches `frac` 0.25 with "
+                         "every issue slot used (`valu_busy` = the share of those slots it does use). The kernel is "
+                         "50 dependent iterations with two team barriers each: latency bound (wait_frac), not pipe or "
+                         "HBM bound."),
                 "launches": auc["launches"], "avg_launch_us": auc["avg_us"],
                 "pairs_per_launch_avg": pairs_rank / auc["launches"],
             }
