@@ -36,17 +36,22 @@ extern "C" {
 #define SN_EINVAL (-22)
 /* a team barrier of an earlier persistent EMD launch on this device gave up (see sn_emd_forward) */
 #define SN_ETIMEDOUT (-110)
-#define SN_ABI_VERSION 3
+#define SN_ABI_VERSION 4
 
 int sn_abi_version(void);
 /* hash of the HIP sources this library was built from (profiles/ measurements carry it) */
 const char *sn_build_id(void);
 /* thread-local text of the last failure on the calling thread ("" if none) */
 const char *sn_last_error(void);
+/* 0, or SN_ETIMEDOUT if a bounded wait inside an earlier multi-workgroup launch (persistent EMD auction, density
+ * sampler teams) on the CURRENT device gave up; clears the condition.  No synchronisation (one word of pinned host
+ * memory is read): call it where the host already waits for the GPU -- after reading a loss value -- to learn about
+ * a time-out in the step that just finished instead of at the next sn_emd_* / sn_mds call. */
+int sn_device_status(void);
 
 /* Optional per-kernel timing, off by default (measurement aid, not part of the
- * reference interface): when enabled the heavy kernels ("chamfer_fwd", "emd_bid",
- * "expansion_fwd", "mds", "p2i_max_splat") are bracketed by hipEventRecord on the
+ * reference interface): when enabled the heavy kernels ("chamfer_fwd", "emd_auction",
+ * "expansion_fwd", "mds", "p2i_max_splat" = the binned gather) are bracketed by hipEventRecord on the
  * stream they are launched on.  sn_prof_read waits for the recorded events and returns
  * the number of launches of `name` since the last reset and their summed duration. */
 void sn_prof_enable(int on);
@@ -114,6 +119,9 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
 size_t sn_emd_workspace_bytes(int b, int n);
 size_t sn_emd_diag_offset(int b, int n);
 int sn_emd_mode(void);
+/* runs the memory-model litmus of the current device now (what the first sn_emd_forward does lazily, on a private
+ * stream, without a device-wide synchronisation) and returns sn_emd_mode()'s answer; -1: undecided (busy device). */
+int sn_emd_selftest(void);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,
                    void *workspace, size_t workspace_bytes,

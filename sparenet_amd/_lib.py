@@ -23,7 +23,7 @@ class SparenetHipError(RuntimeError):
 # The C ABI this Python side was written against (include/sparenet_hip.h: SN_ABI_VERSION).  The library is built
 # separately and is not tracked: a stale .so next to newer Python (or the reverse) would make ctypes pass shifted
 # arguments -- memory corruption instead of an error -- so lib() refuses any other version.
-EXPECTED_ABI = 3
+EXPECTED_ABI = 4
 
 _CTYPES = {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
            "long long": ctypes.c_longlong, "long": ctypes.c_long, "unsigned": ctypes.c_uint, "void": None}

@@ -176,6 +176,18 @@ extern "C" void sn_prof_reset(void) {
 #ifndef SN_BUILD_ID
 #define SN_BUILD_ID "unknown"
 #endif
+// 0, or SN_ETIMEDOUT when a bounded wait of an earlier multi-workgroup launch on the current device gave up (clears the
+// word).  Reads one word of pinned host memory: no synchronisation.  Meaningful AFTER the work in question has
+// finished -- call it where the host already waits for the GPU (reading a loss, an optimiser step's `.item()`).
+extern "C" int sn_device_status(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return sn::check_sticky(dev, "sn_device_status");
+}
+
 extern "C" int sn_abi_version(void) { return SN_ABI_VERSION; }
 extern "C" const char *sn_build_id(void) { return SN_BUILD_ID; }
 extern "C" const char *sn_last_error(void) { return sn::last_error_buf(); }

@@ -34,6 +34,7 @@
 //     reference's +-1e-6 window and its highest-bidder-index rule, awards the target and re-flags the losers.
 //     Two team barriers per iteration instead of three, no separate GetMax pass.
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <mutex>
 
@@ -510,27 +511,29 @@ __device__ __forceinline__ float coarse_threshold(float cm, float base, float a_
 //
 // A launch-per-phase form (bid / GetMax / Assign / compact kernels, 200 launches per call; round 1) pays
 // four kernel boundaries and four cold grids per iteration.  Here a TEAM of G workgroups owns a cloud for
-// the whole call and walks  compact -> bid -> [barrier] -> getmax -> [barrier] -> assign -> [barrier]  with a team barrier
+// the whole call and walks  compact -> bid -> [barrier] -> award (GetMax + Assign) -> [barrier]  with a team barrier
 // (monotonic counter; the exchanged words are read and written with coherent accesses: placement
-// independent) between the phases.
-//   * Workgroup m of a team owns the Morton RANKS [m n/G, (m+1) n/G) of the bidders for the whole call:
-//     it compacts its own raised flags into a local list (no global scan), bids for those bidders, runs
-//     their GetMax / Assign steps.  Its bidders stay spatial neighbours, and the targets near them stay in
-//     its L1 / the team's L2 from one iteration to the next.  The order in which bidders are served never
-//     enters a result (top-2 values, tie keys, atomicMax winners), so this is bit-identical.
-//   * S = 2^k <= 16 waves share one local group of 64 bidders exactly as above.
-//   * The unassigned count of the next iteration (the reference's tie geometry needs it) is accumulated
-//     with one atomic per wave while Assign raises the flags.
+// independent) between the phases: TWO barriers per iteration.
+//   * The Morton RANKS of the bidders are split among the team's workgroups at the top of every iteration
+//     (contiguous ranges of equal load, from the per-bin counters the previous award phase left): a workgroup
+//     compacts the raised flags of its range into a local list (no global scan), bids for those bidders and
+//     walks the target lists whose head it emitted.  Its bidders stay spatial neighbours, and the targets near
+//     them stay in its L1 / the team's L2 from one iteration to the next.  The order in which bidders are served
+//     never enters a result (top-2 values, tie keys, atomicMax winners), so this is bit-identical.
+//   * S = 2^k <= 16 waves share one local group of 64 bidders exactly as above (dense iterations); sparse
+//     iterations serve every bidder with a quarter wave (bid_scan).
 //   * Teams are formed from a TICKET taken at start, not from blockIdx: a workgroup only ever waits for
 //     workgroups that have started, and at most one team per ticket counter is incomplete at any time, so ordinary
 //     kernels on other streams only delay a launch (they finish and free their CUs).  Two TEAM-WAITING launches of
 //     this process never overlap: sn::PersistentLaunch chains them through an event (common.hpp) -- between them
 //     they could otherwise hold every CU of an XCD with members of incomplete teams.
-//     With >= 32 clouds a team is G consecutive tickets of ONE XCD's counter (the XCD read from the hardware
-//     register: its L2 then keeps the cloud's streams; speed only); fewer clouds get larger, contiguous
-//     teams from one global counter.
-//   * Every spin is bounded; a timeout raises ctl.abort, every workgroup of the launch leaves, and
-//     sn_emd_forward reports it on the next call that checks (SN_EMD_CHECK=1: immediately).
+//     A team is G consecutive tickets of ONE XCD's counter for every batch size (the XCD read from the hardware
+//     register: its L2 then keeps the cloud's streams and the team's stores; speed only); devices whose
+//     workgroup count is not a multiple of 64 get contiguous teams from one global counter.
+//   * Every spin is bounded; a time-out raises ctl.abort and the device's sticky word, every workgroup of the
+//     launch leaves, the unfinished clouds get dist = NaN / assignment = -1, and the NEXT sn_emd_* / sn_mds call
+//     on the device -- or sn_device_status() at the caller's own sync point -- returns SN_ETIMEDOUT
+//     (SN_EMD_CHECK=1: the failing call itself synchronises and reports).
 // =======================================================================================
 struct AuctionCtl {  // zeroed by a memset node before every launch
   unsigned ticket;
@@ -1069,7 +1072,8 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
   for (int u0 = 0; u0 < count;) {
     // T quarter waves per bidder: with few bidders left a bidder's superblocks are dealt out to 2 or 4 quarters
     const int rem = count - u0;
-    const int tsh = rem <= 16 ? 2 : (rem <= 32 ? 1 : 0), T = 1 << tsh;  // uniform in the workgroup
+    constexpr int kQuarters = kBidWaves * 4;  // quarter waves of the workgroup (qd below runs over them)
+    const int tsh = rem <= kQuarters / 4 ? 2 : (rem <= kQuarters / 2 ? 1 : 0), T = 1 << tsh;  // uniform in the workgroup
     const int qd = wave * 4 + row;
     const int u = u0 + (qd >> tsh), part = qd & (T - 1);
     const bool active = u < count;  // uniform within the quarter
@@ -1258,7 +1262,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
     }
     if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, c.stash, top, c.eps);
     STAMP(4)
-    u0 += 64 >> tsh;
+    u0 += kQuarters >> tsh;
   }
 #ifdef SN_BID_STAMPS
   if (c.stamps && lane == 0)
@@ -1891,38 +1895,62 @@ __global__ __launch_bounds__(64) void emd_litmus_kernel(unsigned *ctl, unsigned 
 struct DeviceState {
   int verified = 0;       // 0: not yet, 1: fence-free + XCD-local paths verified, 2: fall back (fenced, agent-scope stores)
   int tries = 0;
+  double next_try = 0.0;  // earliest time (steady clock, seconds) of the next attempt after an undecided one
   char why[160] = {0};
 };
 std::mutex g_dev_mu;
 DeviceState g_dev[64];
 
-// runs the litmus on `dev` (synchronises the device once); fills st.verified / st.why
+double now_seconds() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Runs the litmus on `dev`; fills st.verified / st.why.  Everything goes through a PRIVATE non-blocking stream
+// (asynchronous memset, launch and copy, then a wait for that stream only): no null-stream operation, no
+// device-wide synchronisation, nothing that other streams of the process order themselves against.  The caller has
+// checked that ITS stream is not being captured; if some other thread holds a global-mode capture, hipMalloc fails
+// and the test stays undecided (the call at hand takes the fenced path, a later call tries again).  Undecided runs
+// (the grid was not co-resident: a busy device) never latch the slow path: the next attempt is allowed a little
+// later, with a growing pause (0.25 s ... 8 s), so a device that is busy at start-up still gets verified.
 void verify_device(DeviceState &st, int dev, int cus) {
   st.tries++;
+  const double pause = 0.25 * (double)(1 << (st.tries < 6 ? st.tries - 1 : 5));
+  st.next_try = now_seconds() + pause;
   const int W = cus, rounds = 24;
   const size_t words = 64 + (size_t)W + 2 * 8 * (size_t)W * 16 + 16;
   unsigned *buf = nullptr;
+  hipStream_t ps = nullptr;
   if (hipMalloc(reinterpret_cast<void **>(&buf), words * 4) != hipSuccess) {
-    st.verified = 2;
-    snprintf(st.why, sizeof st.why, "self-test: hipMalloc failed");
+    (void)hipGetLastError();
+    snprintf(st.why, sizeof st.why, "self-test: hipMalloc failed (undecided, will retry)");
     return;
   }
-  (void)hipMemset(buf, 0, words * 4);
+  if (hipStreamCreateWithFlags(&ps, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(buf);
+    snprintf(st.why, sizeof st.why, "self-test: no private stream (undecided, will retry)");
+    return;
+  }
   unsigned *ctl = buf, *xcc_of = buf + 64, *aw = xcc_of + W, *pw = aw + 8 * (size_t)W * 16, *res = pw + 8 * (size_t)W * 16;
-  emd_litmus_kernel<<<W, 64, 0, 0>>>(ctl, xcc_of, aw, pw, res, W, rounds);
   unsigned r[16] = {0};
-  const hipError_t e = hipMemcpy(r, res, sizeof r, hipMemcpyDeviceToHost);
+  hipError_t e = hipMemsetAsync(buf, 0, words * 4, ps);
+  if (e == hipSuccess) {
+    emd_litmus_kernel<<<W, 64, 0, ps>>>(ctl, xcc_of, aw, pw, res, W, rounds);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(r, res, sizeof r, hipMemcpyDeviceToHost, ps);
+  if (e == hipSuccess) e = hipStreamSynchronize(ps);
+  (void)hipStreamDestroy(ps);
   (void)hipFree(buf);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     st.verified = 2;
     snprintf(st.why, sizeof st.why, "self-test: %s", hipGetErrorString(e));
     return;
   }
   if (r[2] != 0 || (int)r[3] != W) {  // the grid was not co-resident (busy device): undecided, try again later
-    if (st.tries >= 3) {
-      st.verified = 2;
-      snprintf(st.why, sizeof st.why, "self-test could not run on an idle device (3 tries)");
-    }
+    snprintf(st.why, sizeof st.why, "self-test undecided after %d tries (device busy: %u of %d workgroups ran, %u time-outs)",
+             st.tries, r[3], W, r[2]);
     return;
   }
   if (r[0] != 0 || r[1] != 0) {
@@ -1931,6 +1959,7 @@ void verify_device(DeviceState &st, int dev, int cus) {
     return;
   }
   st.verified = 1;
+  st.why[0] = 0;
 }
 
 }  // namespace
@@ -1964,6 +1993,23 @@ extern "C" int sn_emd_mode(void) {
   return g_dev[dev].verified == 1 ? 0 : -1;
 }
 
+// Explicit start-up self-test of the current device (what the first sn_emd_forward otherwise does lazily): runs the
+// litmus now and returns sn_emd_mode()'s answer (0 / 2), or -1 when the run was undecided (busy device; call again).
+// Call it from the thread that owns the device, outside any graph capture.
+extern "C" int sn_emd_selftest(void) {
+  int dev = 0, cus = 0;
+  SN_HIP(hipGetDevice(&dev));
+  SN_REQUIRE(dev >= 0 && dev < 64, "sn_emd_selftest: unexpected device ordinal %d", dev);
+  SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    DeviceState &st = g_dev[dev];
+    if (st.verified == 0) verify_device(st, dev, cus);
+    (void)hipGetLastError();
+  }
+  return sn_emd_mode();
+}
+
 extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n, float eps,
                               int iters, float *dist, int *assignment, void *workspace,
                               size_t workspace_bytes, long long *stats, void *stream) {
@@ -1989,7 +2035,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     DeviceState &st = g_dev[dev];
-    if (!safe && st.verified == 0) {
+    if (!safe && st.verified == 0 && now_seconds() >= st.next_try) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(s, &cap);
       if (cap == hipStreamCaptureStatusNone) {
@@ -2045,12 +2091,10 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
     {
-      static std::once_flag lds_once[64];  // 101 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced
-      hipError_t lds_rc = hipSuccess;
-      std::call_once(lds_once[dev & 63], [&] {
-        lds_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_auction_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
-      });
+      // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
+      // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.
+      const hipError_t lds_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_auction_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
       SN_REQUIRE(lds_rc == hipSuccess, "sn_emd_forward: hipFuncSetAttribute(%zu bytes of LDS): %s", sizeof(AuctionLds),
                  hipGetErrorString(lds_rc));
       sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
 // Teams are formed from XCD-local tickets like the auction's (emd.hip): the G workgroups of a cloud sit on one
 // XCD whenever the dispatcher allows it, so the words travel through that XCD's L2; any placement is correct.
 // Every poll is bounded: on a time-out the launch raises its abort word and the device's sticky word (the next
-// sn_mds / sn_emd_* call fails with SN_ETIMEDOUT), and the indices not yet picked are written as 0.
+// sn_mds / sn_emd_* call fails with SN_ETIMEDOUT), and the cloud's whole index row is written as -1 (which
+// sn_gather_forward turns into NaN features: never a plausible-looking sample).
 // Only clouds in the dense regime take this path (the predicate is the single-workgroup kernel's, which skips
 // exactly those clouds); index sequences are identical by construction -- the arg-min is order independent.
 // ---------------------------------------------------------------------------------------
@@ -522,7 +523,7 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
   if (tid == 0) {
     int t = -1;
     s_stray = 0;
-    if (xcd_local) {
+    if (xcd_local & 1) {
       const int xcc = (int)(__builtin_amdgcn_s_getreg(20 | (3 << 11)) & 7u);  // HW_REG_XCC_ID
       const int cap = (teams / 8) * G;
       for (int i = 0; i < 9 && t < 0; ++i) {
@@ -544,6 +545,7 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
   if (ticket < 0) return;
   const int b = ticket / G, g = ticket % G;
   if (b >= B || b >= teams) return;
+  if ((xcd_local & 2) && ticket == 1) return;  // test knob (SN_MDS_DIAG=8): a team member that never arrives
   const float *__restrict__ p = xyz + (size_t)b * n * 3;
   const int *__restrict__ perm = perm_all + (size_t)b * n;
   int *__restrict__ out = idxs + (size_t)b * m;
@@ -627,9 +629,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
       if (lane == 0) s_state[0] = __any(missing) ? -1 : (__any(strayed) ? 0 : 1);
     }
     __syncthreads();
-    if (s_state[0] < 0) {
+    if (s_state[0] < 0) {  // the team never formed: nothing of this cloud is a result (-1: sn_gather_* -> NaN)
       if (g == 0)
-        for (int e = tid; e < m; e += 1024) out[e] = 0;
+        for (int e = tid; e < m; e += 1024) out[e] = -1;
       return;
     }
     loc = s_state[0] == 1;
@@ -735,9 +737,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     }
     __syncthreads();
     const int state = s_state[buf];
-    if (state < 0) {  // a member never answered: leave valid indices behind and go (workgroup-uniform)
-      if (g == 0)
-        for (int e = j + tid; e < m; e += 1024) out[e] = 0;
+    if (state < 0) {  // a member never answered (workgroup-uniform): the WHOLE row becomes -1 -- a partial sequence
+      if (g == 0)     // would look like a result; sn_gather_forward turns -1 into NaN, the next sn_mds call fails
+        for (int e = tid; e < m; e += 1024) out[e] = -1;
       return;
     }
     {
@@ -820,7 +822,9 @@ __global__ __launch_bounds__(256) void gather_fwd_kernel(int c, int n, int m,
     const int j = (int)(e % m);
     const long bc = e / m;
     const long b = bc / c;
-    out[e] = feat[bc * n + idx[b * m + j]];
+    const int k = idx[b * m + j];
+    // an index outside the cloud is the sampler's "no result" marker (-1 after a time-out): NaN, not a wild read
+    out[e] = (unsigned)k < (unsigned)n ? feat[bc * n + k] : __builtin_nanf("");
   }
 }
 
@@ -834,7 +838,8 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(int c, int n, int m,
     const int j = (int)(e % m);
     const long bc = e / m;
     const long b = bc / c;
-    unsafeAtomicAdd(&grad_feat[bc * n + idx[b * m + j]], grad_out[e]);
+    const int k = idx[b * m + j];
+    if ((unsigned)k < (unsigned)n) unsafeAtomicAdd(&grad_feat[bc * n + k], grad_out[e]);
   }
 }
 
@@ -913,6 +918,9 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
       if (team_g >= 2) {
         const int pg = (ppt + team_g - 1) / team_g;
         unsigned *sticky = sn::sticky_device_word(dev);
+        // SN_MDS_DIAG=8 (tests): the second member of cloud 0's team leaves at once and the polls give up early
+        const char *dg = getenv("SN_MDS_DIAG");
+        const bool park = dg && atoi(dg) == 8;
         SN_REQUIRE(team_slots * team_g <= 1024, "sn_mds: unexpected team geometry");
         SN_HIP(hipMemsetAsync(tctl, 0, 128 + 128 * 3 * (size_t)team_slots * team_g, s));
         sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
@@ -921,8 +929,8 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_dense_team_kernel<P>),                   \
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));             \
     mds_dense_team_kernel<P><<<team_slots * team_g, 1024, (size_t)P * 8192, s>>>(                           \
-        b, n, m, xyz, perm, bbox, mean_mst_length, idx, tctl, sticky, team_g, team_slots, 1, 1u << 24,      \
-        team_ratio);                                                                                        \
+        b, n, m, xyz, perm, bbox, mean_mst_length, idx, tctl, sticky, team_g, team_slots, park ? 3 : 1,     \
+        park ? 1u << 14 : 1u << 24, team_ratio);                                                            \
   }
         if (pg <= 1) SN_MDST(1)
         else if (pg <= 2) SN_MDST(2)

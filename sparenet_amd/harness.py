@@ -77,9 +77,16 @@ class SurrogateGenerator(torch.nn.Module):
         self.refine2 = SurrogateRefine(batch, num_points, n_primitives)
 
     def forward(self, partial):
+        return self.forward_staged(partial, lambda cloud: None)
+
+    def forward_staged(self, partial, on_cloud):
+        """forward(), calling on_cloud(cloud) as soon as `coarse` and `middle` are final (Completion issues their
+        losses on a second stream while the next refine stage samples)."""
         coarse = self.coarse
         part = partial.transpose(1, 2).contiguous()                      # [B,3,M]
+        on_cloud(coarse)
         middle, loss_mst = self.refine1(coarse.transpose(1, 2).contiguous(), part, coarse)
+        on_cloud(middle)
         refine, _ = self.refine2(middle.transpose(1, 2).contiguous(), part, middle)
         return coarse, middle, refine, loss_mst
 
@@ -104,7 +111,9 @@ class Completion(torch.nn.Module):
         return emd_term(dist)
 
     def forward(self, generator, partial, gt):
-        if self.overlap and partial.is_cuda and isinstance(generator, SurrogateGenerator):
+        # any generator that can hand its clouds over as they become final (SurrogateGenerator, networks.Generator;
+        # a DistributedDataParallel wrapper hides the method on purpose: its forward hooks must run)
+        if self.overlap and partial.is_cuda and hasattr(generator, "forward_staged"):
             return self._forward_overlapped(generator, partial, gt)
         coarse, middle, refine, expansion_penalty = generator(partial)
         coarse_loss, middle_loss, refine_loss = (self._metric(c, gt) for c in (coarse, middle, refine))
@@ -118,22 +127,24 @@ class Completion(torch.nn.Module):
         if self._side is None:
             self._side = torch.cuda.Stream()
         side = self._side
-        coarse = generator.coarse
-        part = partial.transpose(1, 2).contiguous()
+        early = []
         # tensors that cross streams are registered with the caching allocator (record_stream): without it
         # a block freed on its own stream may be handed out again while the other stream still reads it
         gt.record_stream(side)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            coarse_loss = self._metric(coarse, gt)
-        coarse_loss.record_stream(main)
-        middle, expansion_penalty = generator.refine1(coarse.transpose(1, 2).contiguous(), part, coarse)
-        middle.record_stream(side)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            middle_loss = self._metric(middle, gt)
-        middle_loss.record_stream(main)
-        refine, _ = generator.refine2(middle.transpose(1, 2).contiguous(), part, middle)
+
+        def on_cloud(cloud):
+            cloud.record_stream(side)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                loss = self._metric(cloud, gt)
+            loss.record_stream(main)
+            early.append(loss)
+
+        coarse, middle, refine, expansion_penalty = generator.forward_staged(partial, on_cloud)
+        if len(early) == 2:
+            coarse_loss, middle_loss = early
+        else:   # a generator without refine stages hands nothing over early
+            coarse_loss, middle_loss = self._metric(coarse, gt), self._metric(middle, gt)
         refine_loss = self._metric(refine, gt)
         main.wait_stream(side)
         return self._compose(coarse, middle, refine, expansion_penalty, coarse_loss, middle_loss, refine_loss, gt)
@@ -159,7 +170,13 @@ class GanStep:
         self.rng = random.Random(seed)
 
     def _render_views(self, cloud, radius):
-        # [B, views, S, S]: one single-radius map per predefined view, concatenated on dim 1
+        """[B, views, S, S]: one single-radius map per predefined view (runners/sparenet_gan_runner.py:217-225 loops
+        over the views and concatenates on dim 1).  On the GPU all views are ONE pass of the renderer
+        (ComputeDepthMaps.forward_views: the views join the batch; slice v bit-equal to the per-view call, the depth
+        normalisation stays per view and per cloud set) instead of 8 x ~10 short launches."""
+        if cloud.is_cuda and cloud.dtype == torch.float32:
+            maps = self.renderer.forward_views(cloud, range(N_VIEWS_PREDEFINED), [radius])   # [V,B,1,S,S]
+            return maps[:, :, 0].permute(1, 0, 2, 3)
         return torch.cat([self.renderer(cloud, view_id=v, radius_list=[radius])
                           for v in range(N_VIEWS_PREDEFINED)], dim=1)
 

@@ -269,12 +269,19 @@ class Generator(nn.Module):
         self.refine = RefineStage(num_points, n_primitives, use_se) if refine else None
 
     def forward(self, partial):
+        return self.forward_staged(partial, lambda cloud: None)
+
+    def forward_staged(self, partial, on_cloud):
+        """forward(), calling on_cloud(cloud) as soon as `coarse` and `middle` are final: harness.Completion issues
+        their losses on a second HIP stream while the next refine stage's sampler (one workgroup per cloud) runs."""
         part = partial.transpose(1, 2).contiguous()                     # [B,3,M]
         outs = self.decoder(self.encoder(part))                         # [B,3,N]
         coarse = outs.transpose(1, 2).contiguous()
         if self.refine is None:
             return coarse, coarse, coarse, coarse.new_zeros(())
+        on_cloud(coarse)
         middle, loss_mst = self.refine(outs, part, coarse)
+        on_cloud(middle)
         refine, _ = self.refine(middle.transpose(1, 2).contiguous(), part, middle)
         return coarse, middle, refine, loss_mst
 

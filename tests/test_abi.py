@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 28
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/sparenet_hip.h but not exported"
-    assert lib.sn_abi_version() == 3
+    assert lib.sn_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
