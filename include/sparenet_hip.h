@@ -89,6 +89,21 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
                         float *gradxyz1, float *gradxyz2, void *workspace,
                         size_t workspace_bytes, void *stream);
 
+/* Host tensors (replaces cd.forward / cd.backward = chamfer_distance_forward / chamfer_distance_backward,
+ * chamfer_distance.cpp:91-180,185,187 -- the branch ChamferDistanceFunction takes for CPU tensors,
+ * cuda/chamfer_distance/chamfer_distance.py:31-32,53-54; BASELINE config 1).  All pointers are HOST pointers, the
+ * calls are synchronous.  Same values as the device entry points and as the reference's CPU code bit for bit: fp32
+ * distances (dx*dx + dy*dy) + dz*dz without contraction, lowest index among equal minima, the backward's additions in
+ * the reference's order.  threads: worker threads (0 = one per hardware thread; SN_HOST_THREADS overrides).
+ * The library's own host code, not a fallback: device tensors never take this path. */
+int sn_chamfer_forward_host(const float *xyz1, const float *xyz2, int b, int n,
+                            int m, float *dist1, int *idx1, float *dist2,
+                            int *idx2, int threads);
+int sn_chamfer_backward_host(const float *xyz1, const float *xyz2,
+                             const float *graddist1, const float *graddist2,
+                             const int *idx1, const int *idx2, int b, int n, int m,
+                             float *gradxyz1, float *gradxyz2, int threads);
+
 /* ---------------------------------------------------------------------- EMD
  * replaces emd.forward = emd_forward -> emd_cuda_forward
  *          (cuda/emd/emd.cpp:13-17,26; emd_cuda.cu:228-282) including the 12
@@ -122,6 +137,11 @@ int sn_emd_mode(void);
 /* runs the memory-model litmus of the current device now (what the first sn_emd_forward does lazily, on a private
  * stream, without a device-wide synchronisation) and returns sn_emd_mode()'s answer; -1: undecided (busy device). */
 int sn_emd_selftest(void);
+/* Register budget of the persistent auction, process wide: 4 (default) = 128 VGPRs per wave, the auction has its
+ * compute units to itself; 5 = 96 VGPRs per wave, a quarter of every SIMD's registers stays free so that waves of
+ * OTHER launches (the renderer on a second stream) run beside the auction in the issue slots its waves leave idle
+ * while they wait.  Results are bit-identical; the auction alone is ~2 % slower with 5.  SN_EMD_OCC overrides. */
+int sn_emd_set_occupancy(int waves_per_simd);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,
                    void *workspace, size_t workspace_bytes,

@@ -93,8 +93,21 @@ def ptr(t, dtype, name):
     if not t.is_cuda:
         raise SparenetHipError(
             f"{name}: expected a CUDA (ROCm) tensor, got device {t.device}. sparenet_amd runs on "
-            "MI355X only; there is no CPU path (the reference's own CPU Chamfer lives in "
-            "/root/reference/cuda/chamfer_distance/chamfer_distance.cpp).")
+            "MI355X only; there is no CPU path for this op (the reference has none either; only ChamferDistance "
+            "accepts CPU tensors, as in the reference).")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def hptr(t, dtype, name):
+    """HOST pointer of a contiguous CPU tensor (validated) -- only the Chamfer host entry points take these."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if t.is_cuda:
+        raise SparenetHipError(f"{name}: expected a CPU tensor, got device {t.device}")
     if t.dtype != dtype:
         raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():

@@ -437,6 +437,18 @@ __global__ __launch_bounds__(1024) void p2i_bin_grouped_kernel(
     atomicMax(fmax_bits, __float_as_uint(fm));
 }
 
+// Streaming accesses of the renderer's big one-pass arrays (the maps it writes: 8 B per pixel, radius, view and image =
+// 400 MB per sweep at the benched size; the incoming gradient and the winner ids the backward reads once): with
+// SN_P2I_NT they carry the non-temporal hint, so that they do not push the working sets of kernels running BESIDE the
+// renderer (the persistent auction's ~6 MB per XCD) out of the 4 MB L2s.
+#ifdef SN_P2I_NT
+#define SN_STREAM_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
+#define SN_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define SN_STREAM_STORE(ptr, v) (*(ptr) = (v))
+#define SN_STREAM_LOAD(ptr) (*(ptr))
+#endif
+
 #ifdef SN_P2I_DIAG  // statistics of the gather (diag build only)
 __device__ unsigned long long g_gather_diag[8];
 #define GDIAG(...) __VA_ARGS__
@@ -457,6 +469,15 @@ __device__ __forceinline__ float weight32(float u) {
   return __builtin_fmaf(u, p, 0.999999583f);
 }
 constexpr float kWeightErr = 1.5e-6f;
+// weight32(u) + e with e added to the constant term (one instruction less; the sum differs from the two-step form by
+// at most an ulp of 1, far inside the 4e-6 the callers add as a bound's slack)
+__device__ __forceinline__ float weight32_plus(float u, float e) {
+  float p = __builtin_fmaf(u, -0.0102886269f, 0.114825197f);
+  p = __builtin_fmaf(u, p, -0.666184545f);
+  p = __builtin_fmaf(u, p, 2.02902055f);
+  p = __builtin_fmaf(u, p, -2.46737266f);
+  return __builtin_fmaf(u, p, 0.999999583f + e);
+}
 
 // sin(pi t) / (pi t), t = r / R, from u = t^2 in [0, 1], the same way (within 2.3e-7).  The slope of the weight is
 // d/dr = -(pi^2 / 2 R^2) r slope32(u); used by the backward pass only.
@@ -505,6 +526,8 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   const int b = (int)(tile / channels);
   const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
   const bool valid = x < w && y < h;
+  const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
+  (void)valid_mask;
   const size_t plane = ((size_t)b * channels + c) * h * w;
   const float fx = (float)x, fy = (float)y;
   const float eps = __uint_as_float(*fmax_bits) * kWeightErr, band = 2.f * eps;
@@ -531,6 +554,20 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     for (int k = 0; k < NR; ++k) {
       if (!dirty[k]) continue;
       dirty[k] = false;
+#ifdef SN_P2I_V2
+      // float minimum over the wave with the DPP modifier ON the v_min (six instructions: four steps inside the rows
+      // of 16 lanes, row_bcast:15 / row_bcast:31 across them; lane 63 ends up with the minimum).  The values are
+      // finite; pixels outside the image take part as +3e38.  "s_nop 1": a DPP operand written by the previous
+      // vector instruction needs two wait states, which nobody inserts inside inline assembly.
+      float m = valid ? b1[k] : 3.0e38f;
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(m));
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(m));
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(m));
+      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(m));
+      tile_min[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+#else
       unsigned m = valid ? ord_f32(b1[k]) : 0xffffffffu;
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
       m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
@@ -539,6 +576,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
       const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b2_ = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
       const unsigned c2 = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d2 = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
       tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2_), umin_u32(c2, d2)));
+#endif
     }
   };
 #pragma unroll
@@ -594,6 +632,25 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
           const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
           const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
           const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
+#ifdef SN_P2I_V2
+          // lane masks straight from the compares (see the survivor loop); max(cf, 0): weights are >= 0
+          unsigned long long m_end;
+          float cfp;
+          asm("v_cmp_lt_i32_e64 %0, %1, %2" : "=s"(m_end) : "v"(j), "s"(end));
+          asm("v_max_f32 %0, %1, %2" : "=v"(cfp) : "v"(cf), "v"(0.f));
+#pragma unroll
+          for (int k = 0; k < NR; ++k) {
+            // weight32 decreases in u: its value at the nearest pixel (+ its error, folded into the constant term)
+            // bounds the candidate's weights
+            float u;
+            asm("v_min_f32 %0, %1, %2" : "=v"(u) : "v"(smin * ra.inv_r2[k]), "v"(1.0f));
+            const float ub = cfp * weight32_plus(u, 4e-6f);
+            unsigned long long m_r, m_v;
+            asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m_r) : "s"(ra.s_max[k]), "v"(smin));
+            asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m_v) : "s"(tile_min[k]), "v"(ub + band));
+            keep[k] = m_end & m_r & m_v;
+          }
+#else
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             // weight32 decreases in u: its value at the nearest pixel (+ its error) bounds the candidate's weights
@@ -601,6 +658,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
             const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
             keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub + band >= tile_min[k]);
           }
+#endif
         }
         unsigned long long todo = keep[0];
 #pragma unroll
@@ -618,8 +676,49 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
 #pragma unroll
           for (int k = 0; k < NR; ++k) {
             if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
-            const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
             const float a = f * weight32(s2 * ra.inv_r2[k]);  // out of range: a finite value nobody looks at
+#ifdef SN_P2I_V2
+            // Lane masks straight from the compares (inline assembly: through `bool`s hipcc materialises a 0 / 1
+            // vector and compares it again for the wave-level test): in range <=> s2 <= s_max[k] <=> sqrtf(s2) <=
+            // radius[k]; candidate for the top three <=> a >= b1 - band.
+            unsigned long long m_in, m_ge;
+            asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m_in) : "s"(ra.s_max[k]), "v"(s2));
+            asm("v_cmp_ge_f32_e64 %0, %1, %2" : "=s"(m_ge) : "v"(a), "v"(low1[k]));
+            const unsigned long long pass = m_in & m_ge & valid_mask;
+            GDIAG(dg_pairs += __popcll(m_in & valid_mask); dg_upd += __popcll(pass);)
+            if (pass != 0ull) {  // scalar test and branch
+              dirty[k] = true;
+              // Sorted insertion of `a` into b1 >= b2 >= b3 on EVERY lane, as a max / min ladder: lanes outside `pass`
+              // insert -inf, which leaves all three where they are and never wins a (strict) position compare -- also
+              // against a background of -inf.  (A NaN background turns into -inf here; such a pixel never passes
+              // and the epilogue compares against the background itself, so it still comes out as the background.)
+              // Equal values keep their order of arrival, exactly like the compare chain of the other branch.
+              // (inline assembly: hipcc puts a canonicalising v_max(x, x) in front of every fmaxf / fminf on a
+              // loop-carried value; a, b1..b3 are finite -- products of finite numbers -- never NaN)
+              float ae, t, t2, n1, n2, n3;
+              unsigned long long first, second;  // lane masks of ae > b1, ae > b2
+              unsigned posv = pos, e2, nj1, nj2;
+              const float far = -__builtin_inff();
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(ae) : "v"(far), "v"(a), "s"(pass));
+              asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(first) : "v"(ae), "v"(b1[k]));
+              asm("v_cmp_gt_f32_e64 %0, %1, %2" : "=s"(second) : "v"(ae), "v"(b2[k]));
+              asm("v_min_f32 %0, %1, %2" : "=v"(t) : "v"(b1[k]), "v"(ae));
+              asm("v_max_f32 %0, %1, %2" : "=v"(n1) : "v"(b1[k]), "v"(ae));
+              asm("v_min_f32 %0, %1, %2" : "=v"(t2) : "v"(b2[k]), "v"(t));
+              asm("v_max_f32 %0, %1, %2" : "=v"(n2) : "v"(b2[k]), "v"(t));
+              asm("v_max_f32 %0, %1, %2" : "=v"(n3) : "v"(b3[k]), "v"(t2));
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(e2) : "v"(j2[k]), "v"(posv), "s"(second));
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nj2) : "v"(e2), "v"(j1[k]), "s"(first));
+              asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(nj1) : "v"(j1[k]), "v"(posv), "s"(first));
+              j2[k] = nj2;
+              j1[k] = nj1;
+              b1[k] = n1;
+              b2[k] = n2;
+              b3[k] = n3;
+              low1[k] = n1 - band;
+            }
+#else
+            const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
             const bool pass = ink && a >= low1[k];
             GDIAG(dg_pairs += __popcll(__ballot(ink)); dg_upd += __popcll(__ballot(pass));)
             if (__any(pass)) {
@@ -634,6 +733,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
                 low1[k] = b1[k] - band;
               }
             }
+#endif
           }
         }
         refresh_tile_min();
@@ -702,8 +802,8 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     }
     if (valid) {
       const size_t e = (size_t)k * orstride + oplane + (size_t)y * w + x;
-      out[e] = best_v;
-      out_ids[e] = best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low);
+      SN_STREAM_STORE(&out[e], best_v);
+      SN_STREAM_STORE(&out_ids[e], best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low));
     }
   }
   GDIAG(if (lane == 0) {
@@ -1037,8 +1137,8 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   float bg = 0.f;
   for (int k = 0; k < nradii; ++k) {
-    const float gk = valid ? out_grad[(size_t)k * orstride + oe] : 0.f;
-    const int pid = valid ? out_ids[(size_t)k * orstride + oe] : -1;
+    const float gk = valid ? SN_STREAM_LOAD(&out_grad[(size_t)k * orstride + oe]) : 0.f;
+    const int pid = valid ? SN_STREAM_LOAD(&out_ids[(size_t)k * orstride + oe]) : -1;
     if (pid < 0) {
       bg += gk;
       continue;

@@ -3,8 +3,10 @@
 Same public names as the reference (ChamferDistanceFunction :19-61,
 ChamferDistance :64-66, ChamferDistanceMean :69-72, module global `cd` :8-15),
 backed by sn_chamfer_forward / sn_chamfer_backward (include/sparenet_hip.h).
-Difference: GPU tensors only -- a CPU tensor raises instead of taking the
-reference's single-threaded CPU branch (:31-32, :53-54).
+CPU tensors take the branch the reference takes for them (:31-32, :53-54 -> cd.forward /
+cd.backward): the library's own host implementation (sn_chamfer_*_host, csrc/chamfer_host.hip),
+bit-equal to the reference's CPU code.  It is the ONLY op with a host path, because it is the only
+one the reference gives one; CUDA tensors never take it.
 """
 import ctypes
 
@@ -65,11 +67,27 @@ class _CdBinding:
         _lib.check(code, "sn_chamfer_backward")
 
     @staticmethod
-    def forward(*_a, **_k):
-        raise _lib.SparenetHipError(
-            "cd.forward (CPU) is not provided: sparenet_amd is MI355X-only; pass CUDA tensors")
+    def forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+        """cd.forward (chamfer_distance.cpp:91-112): host tensors, caller-allocated outputs."""
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        code = _lib.lib().sn_chamfer_forward_host(
+            _lib.hptr(xyz1, torch.float32, "xyz1"), _lib.hptr(xyz2, torch.float32, "xyz2"), b, n, m,
+            _lib.hptr(dist1, torch.float32, "dist1"), _lib.hptr(idx1, torch.int32, "idx1"),
+            _lib.hptr(dist2, torch.float32, "dist2"), _lib.hptr(idx2, torch.int32, "idx2"), 0)
+        _lib.check(code, "sn_chamfer_forward_host")
 
-    backward = forward
+    @staticmethod
+    def backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+        """cd.backward (chamfer_distance.cpp:114-180): host tensors; the gradients are fully overwritten."""
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        code = _lib.lib().sn_chamfer_backward_host(
+            _lib.hptr(xyz1, torch.float32, "xyz1"), _lib.hptr(xyz2, torch.float32, "xyz2"),
+            _lib.hptr(graddist1, torch.float32, "graddist1"), _lib.hptr(graddist2, torch.float32, "graddist2"),
+            _lib.hptr(idx1, torch.int32, "idx1"), _lib.hptr(idx2, torch.int32, "idx2"), b, n, m,
+            _lib.hptr(gradxyz1, torch.float32, "gradxyz1"), _lib.hptr(gradxyz2, torch.float32, "gradxyz2"), 0)
+        _lib.check(code, "sn_chamfer_backward_host")
 
 
 cd = _CdBinding()
@@ -93,11 +111,16 @@ class ChamferDistanceFunction(torch.autograd.Function):
         xyz1 = xyz1.contiguous().float()
         xyz2 = xyz2.contiguous().float()
         dev = xyz1.device
+        if xyz2.device != dev:
+            raise ValueError("ChamferDistance: xyz1 and xyz2 are on different devices")
         dist1 = torch.empty(batchsize, n, device=dev)
         dist2 = torch.empty(batchsize, m, device=dev)
         idx1 = torch.empty(batchsize, n, dtype=torch.int, device=dev)
         idx2 = torch.empty(batchsize, m, dtype=torch.int, device=dev)
-        cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
+        if not xyz1.is_cuda:      # the reference's branch for CPU tensors (chamfer_distance.py:31-32)
+            cd.forward(xyz1, xyz2, dist1, dist2, idx1, idx2)
+        else:
+            cd.forward_cuda(xyz1, xyz2, dist1, dist2, idx1, idx2)
         ctx.save_for_backward(xyz1, xyz2, idx1, idx2)
         return dist1, dist2
 
@@ -108,7 +131,10 @@ class ChamferDistanceFunction(torch.autograd.Function):
         graddist2 = graddist2.contiguous().float()
         gradxyz1 = torch.empty_like(xyz1)
         gradxyz2 = torch.empty_like(xyz2)
-        cd.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+        if not graddist1.is_cuda:  # chamfer_distance.py:53-54
+            cd.backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
+        else:
+            cd.backward_cuda(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2)
         return gradxyz1, gradxyz2
 
 

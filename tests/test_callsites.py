@@ -71,8 +71,13 @@ def test_every_wrapper_passes_convertible_arguments(stub):
 
     x = torch.rand(2, 1024, 3, requires_grad=True)
     y = torch.rand(2, 1024, 3, requires_grad=True)
-    d1, d2 = ChamferDistance()(x, y)
+    d1, d2 = ChamferDistance()(x, y)          # CPU tensors: the host entry points (sn_chamfer_*_host)
     (d1.sum() + d2.sum()).backward()
+    # the device entry points, as the wrapper calls them for CUDA tensors (the stub's fake pointers stand in)
+    xs, ys = x.detach(), y.detach()
+    e, ei = torch.empty(2, 1024), torch.empty(2, 1024, dtype=torch.int)
+    cd.forward_cuda(xs, ys, e, e.clone(), ei, ei.clone())
+    cd.backward_cuda(xs, ys, torch.empty_like(xs), torch.empty_like(ys), e, e.clone(), ei, ei.clone())
     big = torch.rand(1, 4096, 3)
     cd.forward_sorted_cuda(big, big, torch.empty(1, 4096), torch.empty(1, 4096),
                            torch.empty(1, 4096, dtype=torch.int), torch.empty(1, 4096, dtype=torch.int))
@@ -115,7 +120,8 @@ def test_every_wrapper_passes_convertible_arguments(stub):
     knn_unfused(xf.detach(), 8)
     get_graph_feature(xf, k=8, idx=torch.zeros(1, 128, 8, dtype=torch.int64)).sum().backward()
     called = set(stub.calls)
-    for must in ("sn_chamfer_forward", "sn_chamfer_backward", "sn_chamfer_forward_sorted", "sn_emd_forward",
+    for must in ("sn_chamfer_forward", "sn_chamfer_backward", "sn_chamfer_forward_sorted", "sn_chamfer_forward_host",
+                 "sn_chamfer_backward_host", "sn_emd_forward",
                  "sn_emd_backward", "sn_expansion_forward", "sn_expansion_backward", "sn_mds", "sn_gather_forward",
                  "sn_gather_backward", "sn_p2i_max_forward", "sn_p2i_max_backward", "sn_p2i_sum_forward",
                  "sn_p2i_sum_backward", "sn_p2i_max_forward_f64", "sn_p2i_sum_backward_f64",

@@ -56,6 +56,82 @@ def test_oracle_vs_live_reference_build():
         assert np.array_equal(p, q.numpy())
 
 
+def test_host_path_matches_reference_golden_config1(golden_dir):
+    """BASELINE config 1 as written: ChamferDistance fwd / bwd on CPU tensors (the branch the reference takes for
+    them, chamfer_distance.py:31-32,53-54) -- the library's own host implementation (csrc/chamfer_host.hip), against
+    the goldens of the reference's own CPU build, bit for bit, through the reference's class."""
+    from sparenet_amd.cuda.chamfer_distance import ChamferDistanceFunction
+
+    for f in _golden(golden_dir):
+        z = np.load(f)
+        x = torch.from_numpy(z["xyz1"]).requires_grad_(True)
+        y = torch.from_numpy(z["xyz2"]).requires_grad_(True)
+        d1, d2 = ChamferDistanceFunction.apply(x, y)
+        assert not d1.is_cuda
+        assert np.array_equal(d1.detach().numpy(), z["dist1"]) and np.array_equal(d2.detach().numpy(), z["dist2"]), f
+        torch.autograd.backward([d1, d2], [torch.from_numpy(z["graddist1"]), torch.from_numpy(z["graddist2"])])
+        assert np.array_equal(x.grad.numpy(), z["gradxyz1"]) and np.array_equal(y.grad.numpy(), z["gradxyz2"]), f
+
+
+def test_host_path_edge_cases_match_oracle_and_live_reference():
+    """Ragged sizes (tails of the 8-lane walk), exact ties (lowest index), duplicated points, NaN / inf coordinates
+    (the reference keeps target 0 when nothing compares below it), any thread count -- against the oracle and, where
+    oracle/_ref is built, against the reference's own CPU code."""
+    import ctypes
+
+    import sparenet_amd
+    from oracle import ref
+
+    lib = sparenet_amd.lib()
+    rng = np.random.default_rng(11)
+    cases = []
+    for (b, n, m) in ((1, 1, 1), (2, 7, 9), (3, 257, 1023), (1, 1000, 8), (2, 64, 65)):
+        cases.append((rng.random((b, n, 3), dtype=np.float32), rng.random((b, m, 3), dtype=np.float32)))
+    lat = (rng.integers(0, 3, (2, 300, 3)) * 0.5).astype(np.float32)          # lattice: many exact ties
+    cases.append((lat, np.ascontiguousarray(lat[:, ::-1][:, :211])))
+    nanx, nany = rng.random((1, 40, 3), dtype=np.float32), rng.random((1, 50, 3), dtype=np.float32)
+    nany[0, 0, 1] = np.nan          # target 0 NaN: every query of cloud 1 keeps it
+    nany[0, 19, 0] = np.nan         # a NaN target in the middle of a lane: skipped, its lane goes on
+    nanx[0, 5, 2] = np.inf
+    cases.append((nanx, nany))
+    for x, y in cases:
+        b, n, m = x.shape[0], x.shape[1], y.shape[1]
+        want = oracle.chamfer_forward(x, y)
+        for threads in (1, 3, 0):
+            d1, d2 = np.empty((b, n), np.float32), np.empty((b, m), np.float32)
+            i1, i2 = np.empty((b, n), np.int32), np.empty((b, m), np.int32)
+            vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+            assert lib.sn_chamfer_forward_host(vp(x), vp(y), b, n, m, vp(d1), vp(i1), vp(d2), vp(i2), threads) == 0
+            for got, w in zip((d1, d2, i1, i2), want):
+                assert np.array_equal(got, w, equal_nan=True), (x.shape, y.shape, threads)
+        if ref.available():
+            r = ref.chamfer_forward(torch.from_numpy(x), torch.from_numpy(y))
+            for got, w in zip((d1, d2, i1, i2), r):
+                assert np.array_equal(got, w.numpy(), equal_nan=True)
+        gd1, gd2 = rng.standard_normal((b, n)).astype(np.float32), rng.standard_normal((b, m)).astype(np.float32)
+        g1w, g2w = oracle.chamfer_backward(x, y, gd1, gd2, i1, i2)
+        for threads in (1, 0):
+            g1, g2 = np.full((b, n, 3), 7, np.float32), np.full((b, m, 3), 7, np.float32)   # fully overwritten
+            assert lib.sn_chamfer_backward_host(vp(x), vp(y), vp(gd1), vp(gd2), vp(i1), vp(i2), b, n, m, vp(g1), vp(g2),
+                                                threads) == 0
+            assert np.array_equal(g1, g1w, equal_nan=True) and np.array_equal(g2, g2w, equal_nan=True)
+    bad = np.full((1, 4), 9, np.int32)
+    z = np.zeros((1, 4, 3), np.float32)
+    zz = np.zeros((1, 4), np.float32)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.sn_chamfer_backward_host(vp(z), vp(z), vp(zz), vp(zz), vp(bad), vp(bad), 1, 4, 4, vp(z.copy()), vp(z.copy()), 1) == -22
+    assert b"outside" in lib.sn_last_error()
+
+
+def test_host_path_is_chamfer_only_and_devices_must_agree():
+    from sparenet_amd.cuda.chamfer_distance import ChamferDistance, ChamferDistanceMean
+
+    x = torch.rand(1, 33, 3)
+    assert ChamferDistanceMean()(x, x * 0.5).dim() == 0
+    with pytest.raises(ValueError):
+        ChamferDistance()(x, torch.rand(2, 5, 3))
+
+
 def test_oracle_brute_force_argmin():
     rng = np.random.default_rng(5)
     x = rng.random((2, 97, 3)).astype(np.float32)
@@ -67,14 +143,16 @@ def test_oracle_brute_force_argmin():
     np.testing.assert_allclose(d1, dd.min(2), rtol=1e-6)
 
 
-def test_host_wrapper_rejects_cpu_tensors():
-    from sparenet_amd.cuda.chamfer_distance import ChamferDistance
+def test_host_wrapper_validates_shapes_and_gpu_entry_points_reject_cpu_tensors():
+    from sparenet_amd.cuda.chamfer_distance import ChamferDistance, cd
     from sparenet_amd import SparenetHipError
 
-    with pytest.raises(SparenetHipError):
-        ChamferDistance()(torch.rand(1, 8, 3), torch.rand(1, 8, 3))
     with pytest.raises(ValueError):
         ChamferDistance()(torch.rand(1, 8, 2), torch.rand(1, 8, 3))
+    x = torch.rand(1, 8, 3)
+    d, i = torch.empty(1, 8), torch.empty(1, 8, dtype=torch.int)
+    with pytest.raises(SparenetHipError):     # the DEVICE entry points never take host memory
+        cd.forward_cuda(x, x, d, d.clone(), i, i.clone())
 
 
 # ------------------------------------------------------------------ GPU side

@@ -355,6 +355,59 @@ print("RESULT", int(nan0), int(clean1), raised)
 
 
 @pytest.mark.gpu
+def test_mds_team_timeout_is_loud_without_a_sync():
+    """The sampler's dense-regime teams: a member that never arrives (SN_MDS_DIAG=8 parks the second workgroup of
+    cloud 0's team and shortens the polls) must not leave valid-looking indices behind.  The cloud's WHOLE index row
+    comes back as -1, sn_gather_forward turns those into NaN features (never a wild read), sn_device_status() at the
+    caller's own sync point reports SN_ETIMEDOUT -- and, had nobody asked, the next sn_mds call would."""
+    import subprocess
+    code = _SUBPROCESS_HEAD + r"""
+from sparenet_amd.cuda.MDS.MDS_module import minimum_density_sample, gather_operation
+g = torch.Generator().manual_seed(2)
+x = torch.rand(2, 4096, 3, generator=g).to(dev)
+mml = torch.full((2,), 0.2, device=dev)            # cut ball >> the cube: dense regime, both clouds go to teams
+idx = minimum_density_sample(x, 1024, mml)         # returns normally: nothing is synchronised
+torch.cuda.synchronize()
+row0 = bool((idx[0] == -1).all())
+row1 = bool((idx[1] == -1).all()) or bool(((idx[1] >= 0) & (idx[1] < 4096)).all())
+feat = gather_operation(x.transpose(1, 2).contiguous(), idx)
+nan0 = bool(torch.isnan(feat[0]).all())
+st = L.lib().sn_device_status()
+msg = L.lib().sn_last_error().decode()
+st2 = L.lib().sn_device_status()                   # reading it clears it
+print("RESULT", int(row0), int(row1), int(nan0), int(st == -110 and "timed out" in msg), int(st2 == 0))
+"""
+    env = dict(os.environ)
+    env["SN_MDS_DIAG"] = "8"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stderr[-2000:]
+    assert line[0].split()[1:] == ["1", "1", "1", "1", "1"], (line, out.stderr[-1000:])
+
+
+@pytest.mark.gpu
+def test_emd_shared_occupancy_variant_is_bit_exact(dev):
+    """sn_emd_set_occupancy(5): the auction compiled for 96 VGPRs per wave (room for co-resident launches on its
+    CUs) gives the bits of the 128-register kernel and of the oracle; sn_emd_selftest() agrees with sn_emd_mode()."""
+    import sparenet_amd._lib as L
+
+    x, y = _clouds(5, "uniform", 33)
+    d0, a0 = oracle.emd_forward(x, y, 0.005, 30, mt=True)
+    lib = L.lib()
+    assert lib.sn_emd_selftest() == 0, lib.sn_last_error()
+    assert lib.sn_emd_mode() == 0
+    assert lib.sn_emd_set_occupancy(3) == -22
+    try:
+        assert lib.sn_emd_set_occupancy(5) == 0
+        (d, a), _ = _emd_raw(x, y, 0.005, 30, dev)
+        assert np.array_equal(a.cpu().numpy(), a0) and np.array_equal(d.cpu().numpy(), d0)
+    finally:
+        assert lib.sn_emd_set_occupancy(4) == 0
+    (d, a), _ = _emd_raw(x, y, 0.005, 30, dev)
+    assert np.array_equal(a.cpu().numpy(), a0) and np.array_equal(d.cpu().numpy(), d0)
+
+
+@pytest.mark.gpu
 def test_emd_self_test_passes_and_safe_mode_is_bit_exact(dev):
     """The once-per-device litmus behind the fence-free barriers and the XCD-local plain stores passes on an
     MI355X (sn_emd_mode() == 0 after the first call), and the conservative path it would fall back to -- agent-scope
