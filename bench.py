@@ -522,13 +522,11 @@ def surface_like(b, n, g):
     return torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 
 
-def network_steps(dev):
-    """BASELINE configs 4-5 at their stated sizes (16384 output / 3000 input points, 32 primitives, hide 4096), one
-    rank's share of the 8-GPU job (4 resp. 8 clouds), with the reference's networks restated in
-    sparenet_amd/networks.py (bf16 autocast around the fp32 HIP ops) -- outside the headline region, for the
-    record.  Two decoder states each, because the sampler's regime depends on the coarse cloud: `random_init`
-    (the decoder's output fills the cube: dense regime) and `trained_stand_in` (the decoder's output replaced by a
-    surface-like cloud, its own computation kept in the graph with weight 0: what a trained decoder produces)."""
+def make_network_step(dev, cfg, state, overlap=None):
+    """One rank's share of BASELINE config 4 (reconstruction step, 4 clouds) or config 5 (GAN step, 8 clouds) at the
+    stated sizes, as a callable: forward + backward + optimiser step(s).  state: `random_init` (the decoder's output
+    fills the cube: the sampler's dense regime) or `trained_stand_in` (the decoder's output replaced by a surface-like
+    cloud, its own computation kept in the graph with weight 0: what a trained decoder produces)."""
     from sparenet_amd import networks as nw
     from sparenet_amd.harness import Completion, GanStep
 
@@ -540,6 +538,36 @@ def network_steps(dev):
         def forward(self, style):
             return self.surf + 0.0 * self.dec(style)
 
+    if overlap is None:
+        overlap = os.environ.get("BENCH_NET_OVERLAP", "1") == "1"
+    b = {"config4": 4, "config5": 8}[cfg]
+    g = torch.Generator().manual_seed(4 if cfg == "config4" else 5)
+    gt = surface_like(b, N, g).to(dev)
+    partial = (gt[:, torch.randperm(N, generator=g)[:3000]] + 1e-3 * torch.randn(b, 3000, 3, generator=g).to(dev)).contiguous()
+    torch.manual_seed(0)
+    gen = nw.Generator(num_points=N, n_primitives=32).to(dev)
+    if state == "trained_stand_in":
+        gen.decoder = _StandIn(gen.decoder, (gt + 0.01 * torch.randn(b, N, 3, generator=g).to(dev)).transpose(1, 2).contiguous())
+    opt_g = torch.optim.Adam(gen.parameters(), lr=1e-4)
+    comp = Completion("emd", overlap=overlap).to(dev)
+    if cfg == "config4":
+        def step():
+            loss, *_ = comp(gen, partial, gt)
+            opt_g.zero_grad(set_to_none=True)
+            loss.backward()
+            opt_g.step()
+            return loss
+        return step
+    disc = nw.PatchDiscriminator((16, IMG, IMG)).to(dev)
+    gan = GanStep(gen, disc, comp, opt_g, torch.optim.Adam(disc.parameters(), lr=1e-4))
+    return lambda: gan(partial, gt)
+
+
+def network_steps(dev):
+    """BASELINE configs 4-5 at their stated sizes (16384 output / 3000 input points, 32 primitives, hide 4096), one
+    rank's share of the 8-GPU job (4 resp. 8 clouds), with the reference's networks restated in
+    sparenet_amd/networks.py (bf16 autocast around the fp32 HIP ops) -- outside the headline region, for the
+    record.  Two decoder states each (make_network_step)."""
     spread = {}
 
     def clock(fn, key, reps=5):
@@ -557,33 +585,17 @@ def network_steps(dev):
         spread[key] = {"min": ts[0], "median": ts[len(ts) // 2], "max": ts[-1], "reps": reps}
         return ts[len(ts) // 2]
 
-    g = torch.Generator().manual_seed(4)
     out = {}
-    for cfg, b in (("config4", 4), ("config5", 8)):
-        gt = surface_like(b, N, g).to(dev)
-        partial = (gt[:, torch.randperm(N, generator=g)[:3000]] + 1e-3 * torch.randn(b, 3000, 3, generator=g).to(dev)).contiguous()
+    for cfg in ("config4", "config5"):
         for state in ("random_init", "trained_stand_in"):
-            torch.manual_seed(0)
-            gen = nw.Generator(num_points=N, n_primitives=32).to(dev)
-            if state == "trained_stand_in":
-                gen.decoder = _StandIn(gen.decoder, (gt + 0.01 * torch.randn(b, N, 3, generator=g).to(dev)).transpose(1, 2).contiguous())
-            opt_g = torch.optim.Adam(gen.parameters(), lr=1e-4)
-            comp = Completion("emd", overlap=os.environ.get("BENCH_NET_OVERLAP", "1") == "1").to(dev)
-            if cfg == "config4":
-                def step():
-                    loss, *_ = comp(gen, partial, gt)
-                    opt_g.zero_grad(set_to_none=True)
-                    loss.backward()
-                    opt_g.step()
-            else:
-                disc = nw.PatchDiscriminator((16, IMG, IMG)).to(dev)
-                gan = GanStep(gen, disc, comp, opt_g, torch.optim.Adam(disc.parameters(), lr=1e-4))
-                step = lambda: gan(partial, gt)
+            step = make_network_step(dev, cfg, state)
             out[f"step_ms_{cfg}_{state}"] = clock(step, f"{cfg}_{state}")
-            del gen, opt_g
+            del step
     out["spread_ms"] = spread
-    out["note"] = ("median of 5 individually timed steps (spread_ms: min / median / max); one rank's share of the 8-GPU job: config 4 = 4 clouds (global batch 32), config 5 = 8 clouds (global "
-                   "batch 64); EMD metric; forward + backward + optimiser step(s)")
+    out["note"] = ("median of 5 individually timed steps (spread_ms: min / median / max); one rank's share of the 8-GPU "
+                   "job: config 4 = 4 clouds (global batch 32), config 5 = 8 clouds (global batch 64); EMD metric; forward + "
+                   "backward + optimiser step(s); the loss of each finished cloud overlaps the next refine stage's sampler "
+                   "(harness.Completion, second stream), the GAN step renders all 8 views of a cloud set in one pass")
     return out
 
 

@@ -137,11 +137,6 @@ int sn_emd_mode(void);
 /* runs the memory-model litmus of the current device now (what the first sn_emd_forward does lazily, on a private
  * stream, without a device-wide synchronisation) and returns sn_emd_mode()'s answer; -1: undecided (busy device). */
 int sn_emd_selftest(void);
-/* Register budget of the persistent auction, process wide: 4 (default) = 128 VGPRs per wave, the auction has its
- * compute units to itself; 5 = 96 VGPRs per wave, a quarter of every SIMD's registers stays free so that waves of
- * OTHER launches (the renderer on a second stream) run beside the auction in the issue slots its waves leave idle
- * while they wait.  Results are bit-identical; the auction alone is ~2 % slower with 5.  SN_EMD_OCC overrides. */
-int sn_emd_set_occupancy(int waves_per_simd);
 int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n,
                    float eps, int iters, float *dist, int *assignment,
                    void *workspace, size_t workspace_bytes,

@@ -1309,9 +1309,10 @@ struct AuctionLds {
   ScanLds scan;
 };
 
-// The body is shared by two instantiations that differ only in the register budget the compiler is given
-// (amdgpu_waves_per_eu on the kernels below): 4 waves per SIMD = 128 VGPRs per wave (the auction alone on its CUs),
-// 5 = 96 VGPRs (a quarter of every SIMD's registers left to co-resident launches; sn_emd_set_occupancy).
+// (Round 4 also built this body a second time for 96 VGPRs per wave -- amdgpu_waves_per_eu(5, 5), a quarter of every
+// SIMD's registers left to co-resident launches -- selectable per call: with the quarter-wave scan the 96-register
+// build is 17 % slower ALONE (2.46 against 2.10 ms at 32 clouds, 1.48 against 1.16 at 4: the scan's two candidate
+// rounds in flight spill) and the step with the renderer beside it lost 0.2-0.4 ms; removed)
 __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char auction_lds[];
   AuctionLds &L = *reinterpret_cast<AuctionLds *>(auction_lds);
@@ -1751,12 +1752,6 @@ __global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
                           amdgpu_waves_per_eu(4, 4))) void emd_auction_kernel(AuctionArgs a) {
   auction_body(a);
 }
-// the same auction with 96 VGPRs per wave: other launches' waves fit beside it on every CU
-__global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
-                          amdgpu_waves_per_eu(5, 5))) void emd_auction_shared_kernel(AuctionArgs a) {
-  auction_body(a);
-}
-
 __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
     int B, int n, const float *__restrict__ xyz1, const float *__restrict__ xyz2,
     const float *__restrict__ graddist, const int *__restrict__ assignment,
@@ -1970,23 +1965,7 @@ void verify_device(DeviceState &st, int dev, int cus) {
   st.why[0] = 0;
 }
 
-// 4 or 5 waves per SIMD asked of the compiler for the auction (see auction_body): the process-wide setting of
-// sn_emd_set_occupancy, overridden by SN_EMD_OCC in the environment (A/B runs; read per call).
-std::atomic<int> g_occupancy{4};
-int occupancy_mode() {
-  const char *e = getenv("SN_EMD_OCC");
-  const int v = e ? atoi(e) : g_occupancy.load(std::memory_order_relaxed);
-  return v == 5 ? 5 : 4;
-}
-
 }  // namespace
-
-extern "C" int sn_emd_set_occupancy(int waves_per_simd) {
-  SN_REQUIRE(waves_per_simd == 4 || waves_per_simd == 5, "sn_emd_set_occupancy: 4 (the auction alone on its CUs) or 5 "
-             "(96 VGPRs per wave: room for co-resident launches), got %d", waves_per_simd);
-  g_occupancy.store(waves_per_simd, std::memory_order_relaxed);
-  return 0;
-}
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
@@ -2109,7 +2088,8 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     }
     args.tg = team_geometry(b, cus * kWgPerCu, gmax, legacy);
     args.diag = diag;
-    args.spin_limit = (diag & 8) ? (1u << 15) : kSpinLimit;
+    static const unsigned spin_env = [] { const char *e = getenv("SN_EMD_SPIN_LIMIT"); return e ? (unsigned)atol(e) : 0u; }();
+    args.spin_limit = (diag & 8) ? (1u << 15) : (spin_env ? spin_env : kSpinLimit);   // SN_EMD_SPIN_LIMIT: debugging aid
     args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
@@ -2117,19 +2097,14 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     {
       // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
       // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.
-      // which instantiation: 128 VGPRs per wave, or 96 (sn_emd_set_occupancy / SN_EMD_OCC=5: the caller runs other
-      // launches BESIDE the auction and wants their waves to fit on its CUs)
-      const bool shared_cus = occupancy_mode() == 5;
-      const void *kfn = shared_cus ? reinterpret_cast<const void *>(&emd_auction_shared_kernel)
-                                   : reinterpret_cast<const void *>(&emd_auction_kernel);
-      const hipError_t lds_rc = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
+      // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
+      // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.
+      const hipError_t lds_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_auction_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
       SN_REQUIRE(lds_rc == hipSuccess, "sn_emd_forward: hipFuncSetAttribute(%zu bytes of LDS): %s", sizeof(AuctionLds),
                  hipGetErrorString(lds_rc));
       sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
-      if (shared_cus)
-        SN_TIMED("emd_auction", s, (emd_auction_shared_kernel<<<cus * kWgPerCu, kBidThreads, sizeof(AuctionLds), s>>>(args)));
-      else
-        SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, sizeof(AuctionLds), s>>>(args)));
+      SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, sizeof(AuctionLds), s>>>(args)));
     }
     if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;

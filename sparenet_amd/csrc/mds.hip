@@ -626,7 +626,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
       }
       const bool missing = lane < G && (w & 63ull) != 63ull;
       const bool strayed = lane < G && ((w >> 6) & 1ull) != 0ull;
-      if (lane == 0) s_state[0] = __any(missing) ? -1 : (__any(strayed) ? 0 : 1);
+      // wave-level votes BEFORE the one-lane branch: inside `if (lane == 0)` a vote only sees lane 0
+      const bool any_missing = __any(missing), any_strayed = __any(strayed);
+      if (lane == 0) s_state[0] = any_missing ? -1 : (any_strayed ? 0 : 1);
     }
     __syncthreads();
     if (s_state[0] < 0) {  // the team never formed: nothing of this cloud is a result (-1: sn_gather_* -> NaN)
@@ -730,9 +732,10 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
       const unsigned lw2 = (unsigned)(kmin & 0x3ffffffull);
       const int k = val >= kBig ? 0 : (int)((lw2 >> 1) & 0x7fffu);
       const float px_ = p[k * 3 + 0], py_ = p[k * 3 + 1], pz_ = p[k * 3 + 2];  // uniform address, constant data
+      const bool any_stale = __any(stale);  // voted by the whole wave, not inside the one-lane branch below
       if (lane == 0) {
         s_pick[buf] = make_float4(px_, py_, pz_, __uint_as_float(val >= kBig ? 0u : lw2));
-        s_state[buf] = __any(stale) ? -1 : (val >= kBig ? 0 : 1);
+        s_state[buf] = any_stale ? -1 : (val >= kBig ? 0 : 1);
       }
     }
     __syncthreads();

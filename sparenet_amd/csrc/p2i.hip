@@ -437,18 +437,6 @@ __global__ __launch_bounds__(1024) void p2i_bin_grouped_kernel(
     atomicMax(fmax_bits, __float_as_uint(fm));
 }
 
-// Streaming accesses of the renderer's big one-pass arrays (the maps it writes: 8 B per pixel, radius, view and image =
-// 400 MB per sweep at the benched size; the incoming gradient and the winner ids the backward reads once): with
-// SN_P2I_NT they carry the non-temporal hint, so that they do not push the working sets of kernels running BESIDE the
-// renderer (the persistent auction's ~6 MB per XCD) out of the 4 MB L2s.
-#ifdef SN_P2I_NT
-#define SN_STREAM_STORE(ptr, v) __builtin_nontemporal_store((v), (ptr))
-#define SN_STREAM_LOAD(ptr) __builtin_nontemporal_load(ptr)
-#else
-#define SN_STREAM_STORE(ptr, v) (*(ptr) = (v))
-#define SN_STREAM_LOAD(ptr) (*(ptr))
-#endif
-
 #ifdef SN_P2I_DIAG  // statistics of the gather (diag build only)
 __device__ unsigned long long g_gather_diag[8];
 #define GDIAG(...) __VA_ARGS__
@@ -802,8 +790,8 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     }
     if (valid) {
       const size_t e = (size_t)k * orstride + oplane + (size_t)y * w + x;
-      SN_STREAM_STORE(&out[e], best_v);
-      SN_STREAM_STORE(&out_ids[e], best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low));
+      out[e] = best_v;
+      out_ids[e] = best_low == kBg ? -1 : (int)(0xFFFFFFFEu - best_low);
     }
   }
   GDIAG(if (lane == 0) {
@@ -1137,8 +1125,8 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   float bg = 0.f;
   for (int k = 0; k < nradii; ++k) {
-    const float gk = valid ? SN_STREAM_LOAD(&out_grad[(size_t)k * orstride + oe]) : 0.f;
-    const int pid = valid ? SN_STREAM_LOAD(&out_ids[(size_t)k * orstride + oe]) : -1;
+    const float gk = valid ? out_grad[(size_t)k * orstride + oe] : 0.f;
+    const int pid = valid ? out_ids[(size_t)k * orstride + oe] : -1;
     if (pid < 0) {
       bg += gk;
       continue;

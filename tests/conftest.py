@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 # the persistent auction reports a timed-out team barrier instead of returning garbage (debug aid)
 os.environ.setdefault("SN_EMD_CHECK", "1")
+if os.environ.get("AB_LIB"):   # run the suite against an A/B build of the library (tools/build_variant.sh)
+    import sparenet_amd._lib as _ab
+    _ab.LIB_PATH = os.path.abspath(os.environ["AB_LIB"])
 
 
 def pytest_configure(config):
