@@ -164,7 +164,7 @@ class HotPath:
         self.side = None
         self.side2 = None
         self.hi = None
-        self.order = os.environ.get("BENCH_ORDER", "")   # "auction_first": see _step_auction_first (A/B)
+        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first" / "chain" force an order (A/B); auto: by batch
         self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: by batch
 
     def _emd(self, pred, gt):
@@ -213,7 +213,7 @@ class HotPath:
         teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
         SLOWER whichever side was enqueued first: 2.52-2.54 vs 2.26 ms at 4 clouds, 2.86 vs 2.54 at 8.)"""
         main = torch.cuda.current_stream()
-        if self.order == "auction_first":
+        if self.auction_first(pred.size(0)):
             return self._step_auction_first(pred, gt, main)
         if self.side is None:
             self.side = torch.cuda.Stream()
@@ -243,12 +243,22 @@ class HotPath:
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
         return reduce_mean_of_means(losses)   # RCCL all-reduce over xGMI when N > 1
 
+    def auction_first(self, clouds):
+        """Which order?  The persistent auction needs every CU's registers (16 waves x 128 VGPRs), so nothing runs
+        beside it; what can overlap is everything ELSE.  From 24 clouds per rank on, the auction is enqueued first, on a
+        high-priority stream, and the renderer, Chamfer and the expansion penalty share the chip after it on two more
+        streams (the lone waves of the expansion penalty and Chamfer's search fill the renderer's gaps): 4.90 -> 4.79
+        ms per step at 32 clouds, 4.73 -> 4.58 with round 4's gather (profiles/r04_*_order_ab.txt).  Below that the chain
+        expansion | Chamfer -> auction with the renderer beside it stays (1.57 against 1.77 ms at 4 clouds, 1.97
+        against 2.04 at 8: the auction's teams leave XCDs idle there, and the chain's head overlaps the renderer)."""
+        if self.order in ("auction_first", "chain"):
+            return self.order == "auction_first"
+        return clouds >= 24
+
     def _step_auction_first(self, pred, gt, main):
-        """A/B only (BENCH_ORDER=auction_first; measured and not made the default): the auction
-        on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two more streams
-        beside it.  With a library built with -DSN_EMD_OCC=5 the auction's waves hold 96 VGPRs each, and the other
-        launches' waves fit on the same CUs in the registers it leaves free: the step gains 5 % at 32 clouds while
-        the auction's own launch stretches from 2.6 to 4.5 ms (and the step loses at <= 16 clouds)."""
+        """The auction on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two
+        more streams.  The auction's launch duration measured LIVE includes its wait for the previous step's tail to
+        leave the CUs (`roofline.isolated` is the kernel's own time)."""
         if self.hi is None:
             self.hi = torch.cuda.Stream(priority=-1)
             self.side = self.side or torch.cuda.Stream()
@@ -912,7 +922,10 @@ def main():
                 "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
                 "emd_iters": EMD_ITERS, "radius_list": radius_list,
                 "image": IMG, "views": N_VIEWS,
-                "streams": (3 if hp.three_streams(b_local) else 2) if overlap else 1, "library_build": build_id,
+                "streams": (3 if (hp.three_streams(b_local) or hp.auction_first(b_local)) else 2) if overlap else 1,
+                "order": ("auction first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_first(b_local)
+                          else "expansion | Chamfer -> auction, renderer beside") if overlap else "one stream",
+                "library_build": build_id,
                 "render": "view by view" if args.per_view_render else "8 views in one pass (forward_views)",
             },
             "other_scaling": other,

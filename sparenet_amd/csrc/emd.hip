@@ -397,7 +397,11 @@ struct BidOut {
 #endif
 constexpr int kBidWaves = SN_EMD_BIDWAVES;
 constexpr int kBidThreads = kBidWaves * 64;
+#ifdef SN_EMD_WG_PER_CU   // experiment builds: e.g. ONE 8-wave workgroup per CU, half of every SIMD's registers left free
+constexpr int kWgPerCu = SN_EMD_WG_PER_CU;
+#else
 constexpr int kWgPerCu = 16 / kBidWaves;
+#endif
 constexpr int kStash = kBidThreads;  // list slots whose bid is handed to the award phase through LDS
 
 // What the award phase needs to know about the bid of list slot u (written by the wave that emits the bid, read
@@ -1748,8 +1752,11 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   }
 }
 
+#ifndef SN_EMD_WAVES_PER_EU
+#define SN_EMD_WAVES_PER_EU 4   // 128 VGPRs per wave: 16 waves of one workgroup fill a CU's register files
+#endif
 __global__ __attribute__((amdgpu_flat_work_group_size(kBidThreads, kBidThreads),
-                          amdgpu_waves_per_eu(4, 4))) void emd_auction_kernel(AuctionArgs a) {
+                          amdgpu_waves_per_eu(SN_EMD_WAVES_PER_EU, SN_EMD_WAVES_PER_EU))) void emd_auction_kernel(AuctionArgs a) {
   auction_body(a);
 }
 __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(

@@ -31,7 +31,6 @@ __device__ __forceinline__ unsigned ord_f32(float f) {
   const unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ unsigned umin_u32(unsigned a, unsigned b) { return a < b ? a : b; }
 
 __device__ __forceinline__ float unord_f32(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
@@ -515,7 +514,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
   const bool valid = x < w && y < h;
   const unsigned long long valid_mask = __builtin_amdgcn_ballot_w64(valid);
-  (void)valid_mask;
   const size_t plane = ((size_t)b * channels + c) * h * w;
   const float fx = (float)x, fy = (float)y;
   const float eps = __uint_as_float(*fmax_bits) * kWeightErr, band = 2.f * eps;
@@ -542,7 +540,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     for (int k = 0; k < NR; ++k) {
       if (!dirty[k]) continue;
       dirty[k] = false;
-#ifdef SN_P2I_V2
       // float minimum over the wave with the DPP modifier ON the v_min (six instructions: four steps inside the rows
       // of 16 lanes, row_bcast:15 / row_bcast:31 across them; lane 63 ends up with the minimum).  The values are
       // finite; pixels outside the image take part as +3e38.  "s_nop 1": a DPP operand written by the previous
@@ -555,16 +552,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
       asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(m));
       asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(m));
       tile_min[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
-#else
-      unsigned m = valid ? ord_f32(b1[k]) : 0xffffffffu;
-      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
-      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
-      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x141, 0xf, 0xf, true));  // row_half_mirror
-      m = umin_u32(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x140, 0xf, 0xf, true));  // row_mirror
-      const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)m, 0), b2_ = (unsigned)__builtin_amdgcn_readlane((int)m, 16);
-      const unsigned c2 = (unsigned)__builtin_amdgcn_readlane((int)m, 32), d2 = (unsigned)__builtin_amdgcn_readlane((int)m, 48);
-      tile_min[k] = unord_f32(umin_u32(umin_u32(a, b2_), umin_u32(c2, d2)));
-#endif
     }
   };
 #pragma unroll
@@ -620,7 +607,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
           const float ddx = __builtin_fmaxf(__builtin_fmaxf(tx0 - cpx, cpx - tx1), 0.f);
           const float ddy = __builtin_fmaxf(__builtin_fmaxf(ty0 - cpy, cpy - ty1), 0.f);
           const float smin = (ddx * ddx + ddy * ddy) * 0.99999f;  // <= every pixel's s, with slack
-#ifdef SN_P2I_V2
           // lane masks straight from the compares (see the survivor loop); max(cf, 0): weights are >= 0
           unsigned long long m_end;
           float cfp;
@@ -638,15 +624,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
             asm("v_cmp_le_f32_e64 %0, %1, %2" : "=s"(m_v) : "s"(tile_min[k]), "v"(ub + band));
             keep[k] = m_end & m_r & m_v;
           }
-#else
-#pragma unroll
-          for (int k = 0; k < NR; ++k) {
-            // weight32 decreases in u: its value at the nearest pixel (+ its error) bounds the candidate's weights
-            const float wq = weight32(__builtin_fminf(smin * ra.inv_r2[k], 1.0f)) + 4e-6f;
-            const float ub = cf >= 0.f ? cf * wq : 0.f;  // weights are >= 0
-            keep[k] = __ballot(j < end && smin <= ra.s_max[k] && ub + band >= tile_min[k]);
-          }
-#endif
         }
         unsigned long long todo = keep[0];
 #pragma unroll
@@ -665,7 +642,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
           for (int k = 0; k < NR; ++k) {
             if (!((keep[k] >> i) & 1ull)) continue;  // wave-uniform
             const float a = f * weight32(s2 * ra.inv_r2[k]);  // out of range: a finite value nobody looks at
-#ifdef SN_P2I_V2
             // Lane masks straight from the compares (inline assembly: through `bool`s hipcc materialises a 0 / 1
             // vector and compares it again for the wave-level test): in range <=> s2 <= s_max[k] <=> sqrtf(s2) <=
             // radius[k]; candidate for the top three <=> a >= b1 - band.
@@ -705,23 +681,6 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
               b3[k] = n3;
               low1[k] = n1 - band;
             }
-#else
-            const bool ink = valid && s2 <= ra.s_max[k];  // <=> sqrtf(s2) <= radius[k]
-            const bool pass = ink && a >= low1[k];
-            GDIAG(dg_pairs += __popcll(__ballot(ink)); dg_upd += __popcll(__ballot(pass));)
-            if (__any(pass)) {
-              dirty[k] = true;
-              if (pass) {
-                const bool first = a > b1[k], second = !first && a > b2[k], third = !first && !second && a > b3[k];
-                b3[k] = first || second ? b2[k] : (third ? a : b3[k]);
-                b2[k] = first ? b1[k] : (second ? a : b2[k]);
-                j2[k] = first ? j1[k] : (second ? pos : j2[k]);
-                b1[k] = first ? a : b1[k];
-                j1[k] = first ? pos : j1[k];
-                low1[k] = b1[k] - band;
-              }
-            }
-#endif
           }
         }
         refresh_tile_min();
@@ -1149,9 +1108,16 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
       }
       slot = (slot + 1) & (kAccSlots - 1);
     }
-    const unsigned long long t0 = (unsigned long long)llrint((double)cf * scale);
-    const unsigned long long t1 = (unsigned long long)llrint((double)(kk * dy) * scale);
-    const unsigned long long t2 = (unsigned long long)llrint((double)(kk * dx) * scale);
+    // llrint(x * scale) through the 1.5 * 2^52 trick: scale is a power of two (the product is exact) and every
+    // |term| < 2^44, so rn(x * scale + 1.5 * 2^52) carries rint(x * scale) in its low mantissa bits -- the same
+    // integer as llrint under round-to-nearest-even, in 4 instructions instead of the library's 8 fp64 ones per term
+    auto fixed = [&](float x) {
+      const double m = 6755399441055744.0;  // 1.5 * 2^52
+      return (unsigned long long)(__double_as_longlong(__builtin_fma((double)x, scale, m)) - __double_as_longlong(m));
+    };
+    const unsigned long long t0 = fixed(cf);
+    const unsigned long long t1 = fixed(kk * dy);
+    const unsigned long long t2 = fixed(kk * dx);
     if (found) {
       atomicAdd(&vals[wave][slot][0], t0);
       atomicAdd(&vals[wave][slot][1], t1);
