@@ -604,8 +604,7 @@ def network_steps(dev):
     out["spread_ms"] = spread
     out["note"] = ("median of 5 individually timed steps (spread_ms: min / median / max); one rank's share of the 8-GPU "
                    "job: config 4 = 4 clouds (global batch 32), config 5 = 8 clouds (global batch 64); EMD metric; forward + "
-                   "backward + optimiser step(s); the loss of each finished cloud overlaps the next refine stage's sampler "
-                   "(harness.Completion, second stream), the GAN step renders all 8 views of a cloud set in one pass")
+                   "backward + optimiser step(s); the GAN step renders all 8 views of a cloud set in one pass")
     return out
 
 

@@ -12,7 +12,12 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 step = bench.make_network_step(dev, cfg, state, overlap=os.environ.get("NS_OVERLAP", "1") == "1")
-step(); step()
+for _ in range(int(os.environ.get("NS_WARMUP", "2"))):
+    step()
+torch.cuda.synchronize()
+# the profiler's marker: one kernel that occurs nowhere else (tools/steady_stats.py counts from here on)
+torch.bitwise_xor(torch.arange(4096, device=dev), 12345)
+torch.cuda.synchronize()
 ts = []
 for _ in range(steps):
     torch.cuda.synchronize(); t0 = time.perf_counter()
