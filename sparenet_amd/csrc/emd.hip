@@ -1025,7 +1025,8 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
 // index in any order.
 // ---------------------------------------------------------------------------------------
 #ifndef SN_EMD_SCAN_MAX
-#define SN_EMD_SCAN_MAX 256  // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides)
+#define SN_EMD_SCAN_MAX 384  // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides;
+                             // 128 / 256 / 384 / 512 / 1024: 2.24 / 2.10 / 2.07 / 2.07 / 2.08 ms per call at 32 clouds, r04)
 #endif
 constexpr int kScanBlk = 1024;  // blocks of 16 targets whose boxes fit in the LDS copy (n <= 16384)
 constexpr int kScanList = 64;   // blocks within reach a quarter wave lists before it evaluates them

@@ -362,8 +362,42 @@ def load_reference_state_dict(generator, ref_sd):
     return sorted(k for k in ref_sd if not k.startswith(used_prefixes) or ".adain" in k or "residual.bn7" in k)
 
 
-def _sn(module):
-    return nn.utils.parametrizations.spectral_norm(module)
+class _SpectralNormGemm(nn.utils.parametrizations._SpectralNorm):
+    """torch's spectral-norm parametrization (same buffers, same state_dict keys, one power iteration per training
+    forward as `nn.utils.spectral_norm` in models/sparenet_discriminator.py), with the three matrix-vector products of a
+    forward written as GEMMs with one column, in fp32 outside the autocast region.  On ROCm 7.2 `torch.mv` (aten::addmv_
+    -> rocBLAS gemv) costs 3.7 ms of HOST time per call: 84 calls per GAN step were 311 of config 5's 340 ms of host
+    time, with the GPU busy for 148 ms of a 397 ms step (profiles/r04_*_config5_host_profile.txt)."""
+
+    @staticmethod
+    def _mv(mat, vec):
+        return torch.mm(mat, vec.unsqueeze(1)).squeeze(1)
+
+    @torch.autograd.no_grad()
+    def _power_method(self, weight_mat, n_power_iterations):
+        assert weight_mat.ndim > 1
+        for _ in range(n_power_iterations):
+            self._u = F.normalize(self._mv(weight_mat, self._v), dim=0, eps=self.eps, out=self._u)
+            self._v = F.normalize(self._mv(weight_mat.t(), self._u), dim=0, eps=self.eps, out=self._v)
+
+    def forward(self, weight):
+        if weight.ndim == 1:
+            return F.normalize(weight, dim=0, eps=self.eps)
+        with torch.autocast(weight.device.type, enabled=False):
+            weight_mat = self._reshape_weight_to_matrix(weight.float())
+            if self.training:
+                self._power_method(weight_mat, self.n_power_iterations)
+            u = self._u.clone(memory_format=torch.contiguous_format)
+            v = self._v.clone(memory_format=torch.contiguous_format)
+            sigma = torch.dot(u, self._mv(weight_mat, v))
+            return weight / sigma
+
+
+def _sn(module, name="weight"):
+    weight = getattr(module, name)
+    dim = 1 if isinstance(module, (nn.ConvTranspose1d, nn.ConvTranspose2d, nn.ConvTranspose3d)) else 0
+    nn.utils.parametrize.register_parametrization(module, name, _SpectralNormGemm(weight, 1, dim, 1e-12))
+    return module
 
 
 class PatchDiscriminator(nn.Module):

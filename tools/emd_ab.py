@@ -13,6 +13,20 @@ dev = torch.device("cuda:0")
 N = 16384
 g = torch.Generator().manual_seed(1234)
 X = torch.rand(32, N, 3, generator=g); Y = torch.rand(32, N, 3, generator=g)
+if os.environ.get("AB_DATA") == "surface":
+    # what a training step sees (BASELINE configs 4-5): the ground truth on a surface (a sphere, patch ordered), the
+    # prediction = the ground truth + 1 % noise.  Fewer unassigned bidders per iteration than on uniform cubes, but
+    # contested targets: prices climb, and with them every reach
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    Y = bench.surface_like(32, N, g)
+    X = (Y + float(os.environ.get("AB_NOISE", "0.01")) * torch.randn(32, N, 3, generator=g)).contiguous()
+if os.environ.get("AB_DATA") == "scatter":
+    # early training: the ground truth on a sphere, the prediction scattered around it (uniform offsets up to
+    # AB_NOISE, default 0.3): every bidder is far from every target compared with the targets' spacing
+    import bench
+    Y = bench.surface_like(32, N, g)
+    X = (Y + float(os.environ.get("AB_NOISE", "0.3")) * (2 * torch.rand(32, N, 3, generator=g) - 1)).contiguous()
 mode = "persistent auction"
 if "--parity" in sys.argv:
     for b, iters in ((3, 50), (1, 7), (9, 3)):

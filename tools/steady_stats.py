@@ -10,7 +10,7 @@ path, marker, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 top = int(sys.argv[4]) if len(sys.argv) > 4 else 25
 rows = list(csv.DictReader(open(path)))
 name_k = "Kernel_Name" if "Kernel_Name" in rows[0] else "Name"
-t0 = max((int(r["End_Timestamp"]) for r in rows if marker in r[name_k]), default=None)
+t0 = max((int(r["End_Timestamp"]) for r in rows if marker.lower() in r[name_k].lower()), default=None)
 if t0 is None:
     raise SystemExit(f"marker kernel '{marker}' not found among {len(rows)} dispatches")
 sel = [r for r in rows if int(r["Start_Timestamp"]) >= t0]
