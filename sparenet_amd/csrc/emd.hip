@@ -1054,8 +1054,8 @@ struct ScanCand {  // one round of a quarter wave: lane c holds target c of each
 };
 
 
-__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, int *work_bins, const int *lst, int count,
-                                         int wave, int lane) {
+__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int wave,
+                                         int lane) {
   const int row = lane >> 4, col = lane & 15;
   const int nh = c.nsb >> 2;  // groups of 16 blocks
   const int nblk = c.nsb << 2;
@@ -1127,10 +1127,6 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, int *work
       const bool w = h0 + col < nh && box_within(SL.hb[h][0], SL.hb[h][1], x1, y1, z1, r2);
       hm |= ((__ballot(w) >> (16 * row)) & 0xffffull) << h0;
     }
-    // the work the next iteration's split weighs this bidder's rank bin with: the groups of 256 targets within reach
-    // (x 4: on uniform clouds ~17, the blocks of 16 it then lists).  Taken here, before the loops, so that nothing
-    // more stays live through them.
-    if (active && col == 0 && part == 0) atomicAdd(&work_bins[rank / (c.n / kRankBins)], 4 * (int)__popcll(hm));
     auto fetch = [&](ScanCand &B, int i, int cnt) {
       // the round's four list entries in ONE 8-byte LDS read; entries past the quarter's count are stale or
       // uninitialised words: clamped to a block of this cloud, loaded, and ignored by process()
@@ -1301,7 +1297,6 @@ struct AuctionArgs {
              // second workgroup of team 0 leaves at once and barriers give up early (tests the time-out path).
   long long *dwords;
   int scan_max;  // iterations with at most this many bidders in the workgroup take bid_scan (0: never)
-  int costw;     // 1: the split weighs every bin with the work its bidders needed last iteration (SN_EMD_COSTW=0: counts only)
 };
 
 // The kernel's LDS, carved from the DYNAMIC segment on purpose: with a static 101 KB the compiler derives "one
@@ -1315,7 +1310,7 @@ struct AuctionLds {
   GroupAcc gacc[kBidWaves];
   BidStash stash[kStash];
   int wsum[kBidWaves];
-  int s_flag, s_ticket, s_stray, s_range[5], s_bins[kRankBins], s_cnt[kRankBins];
+  int s_flag, s_ticket, s_stray, s_range[3], s_bins[kRankBins];
   ScanLds scan;
 };
 
@@ -1331,7 +1326,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   BidStash *stash = L.stash;
   int *wsum = L.wsum;
   int &s_flag = L.s_flag, &s_ticket = L.s_ticket, &s_stray = L.s_stray;
-  int *s_range = L.s_range, *s_bins = L.s_bins, *s_cnt = L.s_cnt;
+  int *s_range = L.s_range, *s_bins = L.s_bins;
 #ifdef SN_EMD_PRIO
   __builtin_amdgcn_s_setprio(SN_EMD_PRIO);  // the chain of dependent steps goes first; co-resident waves fill the gaps
 #endif
@@ -1478,65 +1473,44 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
 
     for (int it = 0; it < a.iters; ++it) {
       const int cur = it & 1;
+      // (Round 4 measured a deterministic COST-weighted split here -- every bin weighted with the work bid_scan's
+      // bidders of that bin needed in the previous iteration (groups of 256 targets within reach), so that skewed data
+      // would not leave a team waiting for the workgroup with the expensive bidders: on the scattered-prediction
+      // probe the wait at the first barrier went from 12.9 to 11.5 us per late iteration and the call from 2.59 to
+      // 2.62 ms, on uniform clouds the call got 4-7 % slower (2.03 -> 2.12 ms at 32 clouds: 12 more spilled
+      // registers in a kernel that sits at its 128-VGPR limit).  The imbalance there is in the exact evaluations of
+      // a few bidders with most of the cloud within reach, which a per-bin average does not predict.  Not kept.)
       // The unassigned bidders per 1/256 of the rank range, counted by the previous award phase: every workgroup
       // of the team derives the same split of the ranks into G contiguous, equally loaded ranges (bins are
       // indivisible).  A static split left the team waiting ~20 us per late iteration for the workgroup
       // whose region happened to hold two groups of bidders instead of one.
-      // Weights (round 4): a bin counts with the WORK its bidders needed in the previous iteration -- the groups of
-      // 256 targets within a bidder's reach (x 4), a deterministic count bid_scan leaves per bin -- plus the
-      // fixed cost of a bidder (set-up, box tests, merge: worth ~29 blocks).  On uniform clouds every bin costs the
-      // same and the split is the count split; on skewed data (early training: predictions scattered around a
-      // surface, some bidders with most of the cloud within reach) the team no longer waits for the one workgroup
-      // whose bidders happen to be the expensive ones (bar1 12.9 of 28.9 us per late iteration on the scattered
-      // probe).  Bins without a record (matrix-core iterations, empty bins) count with the uniform case's 17 blocks.
-      // Every workgroup of the team reads the same counters and records and derives the same split.
-      // (the records live in the bidders' sort histogram, which nobody needs once the launch has started: two
-      // buffers of 256 words per cloud, written in the bid phase of iteration `it` at (it & 1), read at the top of the next)
       if (wave == 0) {  // lane l holds the bins 4 l .. 4 l + 3
-        const int *cost_rd = a.ws.hist1 + (size_t)b * kSortCells + ((it & 1) ^ 1) * kRankBins;
         const int2 lo2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane);
         const int2 hi2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane + 2);
-        int cst[4] = {0, 0, 0, 0};
-        if (a.costw && it > 0) {
-          const int2 c0 = ldc2(cost_rd + 4 * lane), c1 = ldc2(cost_rd + 4 * lane + 2);
-          cst[0] = c0.x, cst[1] = c0.y, cst[2] = c1.x, cst[3] = c1.y;
-        }
         const int v[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
-        int w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int cq = cst[q] > 0 ? (cst[q] < 1000 ? cst[q] : 1000) : 17;
-          w[q] = v[q] * (cq + 29);   // <= 4096 x 1029 per bin (n = 2^20): the 256 bins stay below 2^31
-          s_cnt[4 * lane + q] = v[q];
-        }
-        const int lsum = (v[0] + v[1]) + (v[2] + v[3]), lsum_w = (w[0] + w[1]) + (w[2] + w[3]);
-        int incl = lsum, incl_w = lsum_w;
+        const int lsum = (v[0] + v[1]) + (v[2] + v[3]);
+        int incl = lsum;
         for (int d = 1; d < 64; d <<= 1) {
-          const int t = __shfl_up(incl, d), tw = __shfl_up(incl_w, d);
-          if (lane >= d) {
-            incl += t;
-            incl_w += tw;
-          }
+          const int t = __shfl_up(incl, d);
+          if (lane >= d) incl += t;
         }
-        const int total = __shfl(incl, 63), total_w = __shfl(incl_w, 63);
+        const int total = __shfl(incl, 63);
         // a bin goes to the workgroup its MIDPOINT falls to in the ideal split (boundaries land on the bin edge
         // nearest to m total / G): with 256 bins a workgroup's load is within a couple of bidders of total / G,
         // so that it needs a second group of 64 only when the ideal split does
-        int excl = incl_w - lsum_w, first = 0, cnt = 0;
+        int excl = incl - lsum, first = 0, cnt = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          int own = total_w > 0 ? (int)(((long long)(2LL * excl + w[q]) * G) / (2LL * total_w)) : 0;
+          int own = total > 0 ? (int)(((long long)(2 * excl + v[q]) * G) / (2LL * total)) : 0;
           own = own < G - 1 ? own : G - 1;
           first += __popcll(__ballot(own < m));
           cnt += __popcll(__ballot(own == m));
-          excl += w[q];
+          excl += v[q];
         }
         if (lane == 0) {
           s_range[0] = total;
           s_range[1] = first * binsize;
           s_range[2] = cnt * binsize;
-          s_range[3] = first;   // the own bins [first, first + cnt): read back when the work records are written
-          s_range[4] = cnt;
         }
       }
       __syncthreads();
@@ -1623,9 +1597,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
 #endif
         if (scan_ok && Um <= a.scan_max) {  // sparse iteration (uniform in the workgroup): a quarter wave per bidder
-          // (s_bins is free during the bid phase -- the award phase's raise counters, zero outside it -- and takes
-          // the work records)
-          bid_scan(c, L.scan, s_bins, llist, Um, wave, lane);
+          bid_scan(c, L.scan, llist, Um, wave, lane);
         } else {
           const int ngroups = (Um + 63) >> 6;
           int S = 1;
@@ -1638,17 +1610,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           }
         }
       }
-      // the work records of the own bins (single writer per bin and iteration), and the counters back to zero
-      // before the award phase counts its raises in them
-      __syncthreads();
-      if (tid < kRankBins) {
-        if (tid >= s_range[3] && tid < s_range[3] + s_range[4]) {
-          const int cb = s_cnt[tid], wk = s_bins[tid];
-          stc(loc, a.ws.hist1 + (size_t)b * kSortCells + (it & 1) * kRankBins + tid,
-              cb > 0 && wk > 0 ? (wk / cb > 0 ? wk / cb : 1) : 0);
-        }
-        s_bins[tid] = 0;
-      }
+      if (a.diag) __syncthreads();
       tick(6);
       if (!team_barrier(ts, &s_flag)) {
         bail(b);
@@ -2138,8 +2100,6 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
       const char *e = getenv("SN_EMD_SCAN");
       const int v = e ? atoi(e) : SN_EMD_SCAN_MAX;
       args.scan_max = v < 0 ? 0 : v;
-      const char *cw = getenv("SN_EMD_COSTW");
-      args.costw = cw && cw[0] == '0' ? 0 : 1;
     }
     args.tg = team_geometry(b, cus * kWgPerCu, gmax, legacy);
     args.diag = diag;
