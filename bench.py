@@ -860,8 +860,11 @@ def main():
                 # pruned search never evaluates most algorithmic pairs, so this rate can exceed the peak
                 "algorithmic_tflops": achieved, "algorithmic_frac": achieved / PEAK_F32_TFLOPS,
                 "algorithmic_bytes_per_launch": 32.0 * b_local * N,           # 24 B n in + 8 B n out
-                "timing": "live: HIP events on the launch stream inside the timed region (the renderer contends on "
-                          "the second stream); `isolated` = the same launches one stream at a time",
+                "timing": "live: HIP events on the launch stream inside the timed region -- in the auction-first order "
+                          "(>= 24 clouds per rank) the bracket includes the launch's wait for the previous step's "
+                          "renderer to leave the compute units, since the persistent grid needs all of them; "
+                          "`isolated` = the same launches one stream at a time = the kernel's own duration (what "
+                          "rocprofv3's kernel table shows)",
                 "note": ("`achieved` / `frac` = executed work (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 + SQ_INSTS_VALU x 64 "
                          "per launch, every vector instruction counted as 64 useful lanes) / live launch time / fp32 "
                          "peak (vector = f32 MFMA dense peak); null when no counters of this build are committed. "

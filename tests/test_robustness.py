@@ -105,18 +105,28 @@ print("EMD_REFUSED", refused)
 
 
 @pytest.mark.gpu
-def test_chamfer_library_calls_replay_bit_identically_from_a_graph():
-    """What round 4 established about the graph failures (tools/capture_probe.py): the Chamfer LIBRARY calls
-    themselves -- sort + prepare + pruned search, and the backward's lists / gather / long-list kernels with 131 KB of
-    dynamic LDS and a memset node -- capture and replay TWICE bit-identically on caller-owned buffers
-    (SN_ALLOW_CAPTURE=1 lifts the refusal); the memory fault of round 3 only appears on the SECOND replay of a graph
-    that also holds the autograd engine's nodes (forward + backward through the Python wrapper), like the auction,
-    whose first replay is bit-identical and whose second one never returns.  The refusals therefore stay, and this
-    test pins the part that is sound."""
+def test_library_calls_replay_bit_identically_from_hip_graphs():
+    """What round 4 established about graph replay.  Through the RAW HIP graph API (tools/probe/graph_emd.hip: stream
+    capture of the C-ABI calls, hipGraphInstantiate, three hipGraphLaunch) the persistent auction and Chamfer forward +
+    backward replay bit-identically every time, on a side stream or the null stream, with or without
+    AutoFreeOnLaunch.  Under torch.cuda.CUDAGraph (PyTorch 2.10 on ROCm 7.2) the SAME captured calls replay once and
+    the second replay hangs (auction) or faults (Chamfer forward + backward through autograd) -- below the library,
+    which is why the refusals stay the default (SN_ALLOW_CAPTURE=1 lifts them for HIP-level graphs) -- while the
+    Chamfer calls on caller-owned buffers replay twice there as well (tools/capture_probe.py)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "probe", "graph_emd")
+    if not os.path.isfile(exe):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", exe + ".hip", "-I" + os.path.join(root, "include"),
+                               "-L" + os.path.join(root, "sparenet_amd"), "-lsparenet_hip",
+                               "-Wl,-rpath," + os.path.join(root, "sparenet_amd"), "-o", exe])
     env = dict(os.environ, SN_ALLOW_CAPTURE="1")
-    for case in ("chamfer_fwd_sorted", "chamfer_bwd"):
+    env.pop("SN_EMD_CHECK", None)       # the check synchronises: not allowed inside a capture
+    for args in (["emd"], ["emd", "null+autofree"], ["chamfer"]):
+        out = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=300)
+        lines = [l for l in out.stdout.splitlines() if l.startswith("replay") and "equal to eager" in l]
+        assert len(lines) == 3 and all(l.endswith("equal to eager: 1") for l in lines), (args, out.stdout[-600:], out.stderr[-400:])
+    for case in ("chamfer_fwd_sorted", "chamfer_bwd"):     # and under torch.cuda.CUDAGraph, caller-owned buffers
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "capture_probe.py"), case], env=env,
                              capture_output=True, text=True, timeout=300)
         lines = [l for l in out.stdout.splitlines() if "replay" in l]

@@ -1,5 +1,5 @@
 """One pass of every hot op at the benched sizes, for profiler passes (tools/pmc_all.sh, tools/kstats.sh).
-Env: PROBE_MDS=0 skips the sampler, PROBE_VIEWS (default 2) renderer views."""
+Env: PROBE_MDS=0 skips the sampler, PROBE_VIEWS=<n> renders n views one by one instead of 8 in one pass."""
 import os
 import sys
 
@@ -33,9 +33,14 @@ for rep in range(int(os.environ.get("PROBE_REPS", "2"))):
     dist, _ = emdModule()(p, gt, 0.005, 50)
     torch.sqrt(dist).mean().backward()
     p4 = (pred - 0.5).requires_grad_(True)
-    acc = 0
-    for v in range(int(os.environ.get("PROBE_VIEWS", "2"))):
-        acc = acc + render(p4, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
+    # all 8 views in one pass, as bench.py renders them: the counters of a gather dispatch then describe the launch
+    # bench.py times (PROBE_VIEWS=<n>: the reference's view-by-view loop over n views instead)
+    if os.environ.get("PROBE_VIEWS"):
+        acc = 0
+        for v in range(int(os.environ["PROBE_VIEWS"])):
+            acc = acc + render(p4, view_id=v, radius_list=[5.0, 7.0, 10.0]).mean()
+    else:
+        acc = render.forward_views(p4, range(8), [5.0, 7.0, 10.0]).mean() * 8
     acc.backward()
     torch.cuda.synchronize()
 if os.environ.get("PROBE_MDS", "1") != "0":
