@@ -57,6 +57,11 @@ int sn_device_status(void);
 void sn_prof_enable(int on);
 long long sn_prof_read(const char *name, double *total_ms);
 void sn_prof_reset(void);
+/* With sn_prof_enable(1) the persistent EMD auction also records its own EXECUTION window (first working workgroup's
+ * start to the last one's end, in-kernel 100 MHz clock): launches since the last reset on the current device and the
+ * sum of the windows.  The HIP-event bracket of "emd_auction" additionally contains the launch's wait for compute
+ * units (the grid needs every CU empty), i.e. the schedule around it. */
+long long sn_emd_prof_exec(double *total_ms, int reset);
 
 /* ------------------------------------------------------------------ Chamfer
  * replaces cd.forward_cuda  = chamfer_distance_forward_cuda

@@ -543,7 +543,10 @@ struct AuctionCtl {  // zeroed by a memset node before every launch
   unsigned ticket;
   unsigned abort;
   unsigned xticket[8];  // one ticket counter per XCD (teams of the XCD-local geometry)
-  unsigned pad[22];
+  // measurement aid (sn_prof_enable): the launch's own execution window in 100 MHz ticks -- ~(earliest start of a
+  // working workgroup) and the latest end, both as running maxima so that the zeroed block is their neutral element
+  unsigned long long t_first_inv, t_last;
+  unsigned pad[18];
   unsigned bar[1];  // [teams * 32]: one counter per team, 128 bytes apart
 };
 
@@ -1297,6 +1300,7 @@ struct AuctionArgs {
              // second workgroup of team 0 leaves at once and barriers give up early (tests the time-out path).
   long long *dwords;
   int scan_max;  // iterations with at most this many bidders in the workgroup take bid_scan (0: never)
+  int prof;      // 1: record the execution window in the control block (sn_prof_enable)
 };
 
 // The kernel's LDS, carved from the DYNAMIC segment on purpose: with a static 101 KB the compiler derives "one
@@ -1369,6 +1373,8 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   if (ticket < 0) return;  // no slot left: surplus workgroup of a grid larger than teams x G
   const int team = ticket / G, m = ticket % G;
   if (team >= a.tg.teams || team >= a.B) return;  // a team without a cloud (fewer clouds than teams)
+  if (a.prof && tid == 0)
+    atomicMax(&a.ctl->t_first_inv, ~(unsigned long long)__builtin_amdgcn_s_memrealtime());
   if ((a.diag & 8) && ticket == 1) return;        // test knob: a team member that never arrives
   const int n = a.n, nsb = n >> 6;
   TeamSync ts = {a.ctl->bar + (size_t)team * 32, &a.ctl->abort, a.sticky, 0u, a.spin_limit, G, a.safe};
@@ -1758,6 +1764,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
     }
     // a team that serves several clouds: the flags / lists of the next cloud are its own, nothing to wait for
   }
+  if (a.prof && tid == 0) atomicMax(&a.ctl->t_last, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 }
 
 #ifndef SN_EMD_WAVES_PER_EU
@@ -1980,7 +1987,49 @@ void verify_device(DeviceState &st, int dev, int cus) {
   st.why[0] = 0;
 }
 
+// The launch's own execution window, added to a per-device accumulator {ticks, launches} by a one-thread launch behind
+// the auction (measurement aid: only with sn_prof_enable).  HIP events around the launch also contain its wait for
+// compute units -- the persistent grid needs every CU empty, and in bench.py's auction-first order the previous step's
+// renderer is still draining when the launch is enqueued -- which says something about the schedule, not the kernel.
+__global__ void emd_exec_window_kernel(const AuctionCtl *ctl, unsigned long long *acc) {
+  const unsigned long long first = ~ctl->t_first_inv, last = ctl->t_last;
+  if (ctl->t_first_inv != 0ull && last > first) {
+    acc[0] += last - first;
+    acc[1] += 1ull;
+  }
+}
+std::mutex g_exec_mu;
+unsigned long long *g_exec_acc[64] = {nullptr};
+unsigned long long *exec_accumulator(int dev) {  // nullptr if it cannot be allocated (then nothing is recorded)
+  std::lock_guard<std::mutex> lk(g_exec_mu);
+  if (!g_exec_acc[dev]) {
+    void *p = nullptr;
+    if (hipMalloc(&p, 16) == hipSuccess && hipMemset(p, 0, 16) == hipSuccess) g_exec_acc[dev] = static_cast<unsigned long long *>(p);
+    else (void)hipGetLastError();
+  }
+  return g_exec_acc[dev];
+}
+
 }  // namespace
+
+// measurement aid next to sn_prof_read("emd_auction"): launches recorded since the last reset on the current device and
+// the sum of their execution windows (first working workgroup's start to the last one's end, in-kernel 100 MHz clock)
+extern "C" long long sn_emd_prof_exec(double *total_ms, int reset) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  unsigned long long *acc = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(g_exec_mu);
+    acc = g_exec_acc[dev];
+  }
+  unsigned long long v[2] = {0, 0};
+  if (acc) {
+    if (hipMemcpy(v, acc, 16, hipMemcpyDeviceToHost) != hipSuccess) (void)hipGetLastError();
+    if (reset) (void)hipMemset(acc, 0, 16);
+  }
+  if (total_ms) *total_ms = (double)v[0] * 1e-5;
+  return (long long)v[1];
+}
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
@@ -2118,8 +2167,15 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AuctionLds));
       SN_REQUIRE(lds_rc == hipSuccess, "sn_emd_forward: hipFuncSetAttribute(%zu bytes of LDS): %s", sizeof(AuctionLds),
                  hipGetErrorString(lds_rc));
+      unsigned long long *exec_acc = nullptr;
+      args.prof = 0;
+      if (sn::prof_enabled() && !sn::capturing(s)) {
+        exec_acc = exec_accumulator(dev);
+        args.prof = exec_acc != nullptr;
+      }
       sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
       SN_TIMED("emd_auction", s, (emd_auction_kernel<<<cus * kWgPerCu, kBidThreads, sizeof(AuctionLds), s>>>(args)));
+      if (args.prof) emd_exec_window_kernel<<<1, 1, 0, s>>>(args.ctl, exec_acc);
     }
     if (check) {  // debugging aid: wait for the launch and report a time-out at once
       unsigned abort_word = 0;

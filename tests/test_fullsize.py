@@ -386,6 +386,37 @@ print("RESULT", int(row0), int(row1), int(nan0), int(st == -110 and "timed out" 
 
 
 @pytest.mark.gpu
+def test_emd_execution_window_is_recorded_when_profiling(dev):
+    """sn_prof_enable(1): the persistent auction records its own execution window (in-kernel clock) next to the
+    HIP-event bracket; both count the launches, the window is positive and not longer than the bracket (which also
+    holds the launch's wait for compute units), and results do not change."""
+    import ctypes
+    import sparenet_amd._lib as L
+
+    lib = L.lib()
+    x, y = _clouds(4, "uniform", 17)
+    d0, a0 = oracle.emd_forward(x, y, 0.005, 20, mt=True)
+    _emd_raw(x, y, 0.005, 20, dev)          # warm (self-test, allocations)
+    torch.cuda.synchronize()
+    lib.sn_prof_reset()
+    lib.sn_emd_prof_exec(None, 1)
+    lib.sn_prof_enable(1)
+    try:
+        for _ in range(3):
+            (d, a), _ = _emd_raw(x, y, 0.005, 20, dev)
+        torch.cuda.synchronize()
+    finally:
+        lib.sn_prof_enable(0)
+    assert np.array_equal(a.cpu().numpy(), a0) and np.array_equal(d.cpu().numpy(), d0)
+    ev, ex = ctypes.c_double(0.0), ctypes.c_double(0.0)
+    n_ev = lib.sn_prof_read(b"emd_auction", ctypes.byref(ev))
+    n_ex = lib.sn_emd_prof_exec(ctypes.byref(ex), 1)
+    assert n_ev == 3 and n_ex == 3, (n_ev, n_ex)
+    assert 0.05 < ex.value <= ev.value * 1.05, (ex.value, ev.value)
+    assert lib.sn_emd_prof_exec(ctypes.byref(ex), 0) == 0 and ex.value == 0.0     # the read above reset it
+
+
+@pytest.mark.gpu
 def test_emd_self_test_passes_and_safe_mode_is_bit_exact(dev):
     """The once-per-device litmus behind the fence-free barriers and the XCD-local plain stores passes on an
     MI355X (sn_emd_mode() == 0 after the first call), and the conservative path it would fall back to -- agent-scope

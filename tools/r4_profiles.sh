@@ -18,7 +18,7 @@ r = d["roofline"]
 print({k: d[k] for k in ("value", "ms_per_step", "depthmaps_per_sec", "depthmaps_per_sec_literal_radii", "sequential_ms_per_step_rank0")})
 print("config", d["config"].get("order"), d["config"].get("streams"))
 print("segments", d["segments_ms_rank0"])
-print("roofline", {k: r.get(k) for k in ("kernel", "bound", "achieved", "frac", "algorithmic_frac", "wait_frac", "valu_busy", "mfma_busy", "traffic", "avg_launch_us", "counters_from")}, "isolated", r.get("isolated"))
+print("roofline", {k: r.get(k) for k in ("kernel", "bound", "achieved", "frac", "algorithmic_frac", "wait_frac", "valu_busy", "mfma_busy", "traffic", "avg_launch_us", "bracket_avg_us", "queue_wait_avg_us", "counters_from")}, "isolated", r.get("isolated"))
 for k in ("chamfer_fwd", "p2i_gather_max", "mds_clustered"):
     print(k, {a: r[k].get(a) for a in ("frac", "algorithmic_frac", "valu_busy", "wait_frac", "avg_launch_us", "traffic") if a in r[k]})
 print("literal", d.get("literal_radii"))
@@ -29,7 +29,7 @@ echo "== rocprofv3 --kernel-trace --stats of the bench command"
 cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/kst -- python $R/bench.py --no-other-ops --no-cpu-baseline --no-network-steps --no-literal-radii --steps 10 --warmup 2 > /dev/null 2>&1; cd $R
 f=$(find gpurun_out/kst -name "*kernel_stats.csv" | head -1); cp $f $O/kernel_stats.csv; head -8 $f | cut -c1-160; rm -rf gpurun_out/kst
 echo "== stream order A/B"
-line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_rank0']; ki=d['kernels_isolated_rank0']; print(round(d['ms_per_step'],3), 'ms per step; one stream', round(d['sequential_ms_per_step_rank0'],3), '; auction live / isolated us', round(k['emd_auction']['avg_us']), round(ki['emd_auction']['avg_us']), '; gather live / isolated us', round(k['p2i_max_splat']['avg_us']), round(ki['p2i_max_splat']['avg_us']))"; }
+line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernels_rank0']; ki=d['kernels_isolated_rank0']; print(round(d['ms_per_step'],3), 'ms per step; one stream', round(d['sequential_ms_per_step_rank0'],3), '; auction bracket / execution window / isolated us', round(k['emd_auction']['avg_us']), round(k['emd_auction_exec']['avg_us']), round(ki['emd_auction']['avg_us']), '; gather live / isolated us', round(k['p2i_max_splat']['avg_us']), round(ki['p2i_max_splat']['avg_us']))"; }
 BA="--no-cpu-baseline --no-other-ops --no-network-steps --no-literal-radii --steps 30 --warmup 8"
 for o in chain auction_first; do echo -n "BENCH_ORDER=$o: "; BENCH_ORDER=$o timeout 300 python bench.py $BA 2>/dev/null | line; done | tee $O/order_ab.txt
 echo "== emd phases + per batch size"
