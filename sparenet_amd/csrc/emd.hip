@@ -1920,6 +1920,8 @@ __global__ __launch_bounds__(64) void emd_litmus_kernel(unsigned *ctl, unsigned 
 struct DeviceState {
   int verified = 0;       // 0: not yet, 1: fence-free + XCD-local paths verified, 2: fall back (fenced, agent-scope stores)
   int tries = 0;
+  int cus = 0;            // compute units the verdict was reached with: a different count (a compute-partition mode
+                          // change between calls gives the same ordinal another shape) voids it
   double next_try = 0.0;  // earliest time (steady clock, seconds) of the next attempt after an undecided one
   char why[160] = {0};
 };
@@ -1939,6 +1941,7 @@ double now_seconds() {
 // later, with a growing pause (0.25 s ... 8 s), so a device that is busy at start-up still gets verified.
 void verify_device(DeviceState &st, int dev, int cus) {
   st.tries++;
+  st.cus = cus;
   const double pause = 0.25 * (double)(1 << (st.tries < 6 ? st.tries - 1 : 5));
   st.next_try = now_seconds() + pause;
   const int W = cus, rounds = 24;
@@ -2071,6 +2074,7 @@ extern "C" int sn_emd_selftest(void) {
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     DeviceState &st = g_dev[dev];
+    if (st.verified != 0 && st.cus != cus) st = DeviceState{};
     if (st.verified == 0) verify_device(st, dev, cus);
     (void)hipGetLastError();
   }
@@ -2102,6 +2106,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     DeviceState &st = g_dev[dev];
+    if (st.verified != 0 && st.cus != cus) st = DeviceState{};   // the device changed shape: verify again
     if (!safe && st.verified == 0 && now_seconds() >= st.next_try) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       (void)hipStreamIsCapturing(s, &cap);
