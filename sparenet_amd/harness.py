@@ -116,7 +116,7 @@ class Completion(torch.nn.Module):
         # only: the EMD auction is one persistent launch that needs EVERY compute unit (a team of 32 workgroups per
         # XCD), so beside the sampler -- one workgroup per cloud for ~18 ms -- its teams spin until the sampler's CUs
         # are free: measured, rocprofv3 shows 17.7 ms per auction launch instead of 1.2 and the step does not move
-        # (config 4: 141 ms either way, profiles/r04_b_network_config4_steady.txt)
+        # (config 4: 141 ms either way, profiles/r04_c_network_config4_steady.txt)
         if self.overlap and self.metric == "chamfer" and partial.is_cuda and hasattr(generator, "forward_staged"):
             return self._forward_overlapped(generator, partial, gt)
         coarse, middle, refine, expansion_penalty = generator(partial)

@@ -367,7 +367,7 @@ class _SpectralNormGemm(nn.utils.parametrizations._SpectralNorm):
     forward as `nn.utils.spectral_norm` in models/sparenet_discriminator.py), with the three matrix-vector products of a
     forward written as GEMMs with one column, in fp32 outside the autocast region.  On ROCm 7.2 `torch.mv` (aten::addmv_
     -> rocBLAS gemv) costs 3.7 ms of HOST time per call: 84 calls per GAN step were 311 of config 5's 340 ms of host
-    time, with the GPU busy for 148 ms of a 397 ms step (profiles/r04_b_config5_host_profile.txt)."""
+    time, with the GPU busy for 148 ms of a 397 ms step (profiles/r04_c_config5_host_profile.txt)."""
 
     @staticmethod
     def _mv(mat, vec):
