@@ -248,9 +248,10 @@ class HotPath:
         beside it; what can overlap is everything ELSE.  From 24 clouds per rank on, the auction is enqueued first, on a
         high-priority stream, and the renderer, Chamfer and the expansion penalty share the chip after it on two more
         streams (the lone waves of the expansion penalty and Chamfer's search fill the renderer's gaps): 4.90 -> 4.79
-        ms per step at 32 clouds, 4.73 -> 4.58 with round 4's gather (profiles/r04_c_order_ab.txt).  Below that the chain
-        expansion | Chamfer -> auction with the renderer beside it stays (1.57 against 1.77 ms at 4 clouds, 1.97
-        against 2.04 at 8: the auction's teams leave XCDs idle there, and the chain's head overlaps the renderer)."""
+        ms per step at 32 clouds, 4.62 -> 4.46 with round 4's gather (profiles/r04_c_share_by_order.txt).  Below that the chain
+        expansion | Chamfer -> auction with the renderer beside it stays (16 / 8 / 4 clouds: 3.18 / 1.96 / 1.54-1.65 ms
+        against 3.16-3.45 / 2.01 / 1.78: the auction's teams leave XCDs idle there, and the chain's head overlaps the
+        renderer)."""
         if self.order in ("auction_first", "chain"):
             return self.order == "auction_first"
         return clouds >= 24
