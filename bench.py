@@ -533,6 +533,45 @@ def surface_like(b, n, g):
     return torch.gather(v, 1, key.argsort(dim=1).unsqueeze(-1).expand(-1, -1, 3)).contiguous()
 
 
+EMD_REGIMES = ("uniform", "surface", "scatter", "untrained")
+_UNTRAINED_CACHE = {}
+
+
+def emd_regime_clouds(name, b, dev, seed=1234):
+    """(prediction, ground truth), [b, N, 3] each: the four kinds of data a training run hands the auction.
+    uniform   -- two independent uniform cubes (the benchmark's clouds; make_inputs draws the same numbers);
+    surface   -- ground truth on a sphere in 512-point patches, prediction = ground truth + 1 % noise (a trained generator);
+    scatter   -- prediction = ground truth + uniform offsets up to +-0.3 (early training);
+    untrained -- the `refine` output of networks.Generator at RANDOM INIT on a partial view of that ground truth
+                 (residual offsets up to +-1: what configs 4-5 feed the auction in the first steps of every run)."""
+    g = torch.Generator().manual_seed(seed)
+    if name == "uniform":
+        x = torch.rand(b, N, 3, generator=g)
+        y = torch.rand(b, N, 3, generator=g)
+        return x.to(dev), y.to(dev)
+    gt = surface_like(b, N, g)
+    if name == "surface":
+        return (gt + 0.01 * torch.randn(b, N, 3, generator=g)).contiguous().to(dev), gt.to(dev)
+    if name == "scatter":
+        return (gt + 0.3 * (2 * torch.rand(b, N, 3, generator=g) - 1)).contiguous().to(dev), gt.to(dev)
+    if name != "untrained":
+        raise ValueError(name)
+    key = (b, seed, str(dev))
+    if key not in _UNTRAINED_CACHE:
+        from sparenet_amd import networks as nw
+        gtd = gt.to(dev)
+        partial = (gtd[:, torch.randperm(N, generator=g)[:3000]] + 1e-3 * torch.randn(b, 3000, 3, generator=g).to(dev)).contiguous()
+        torch.manual_seed(0)
+        gen = nw.Generator(num_points=N, n_primitives=32).to(dev).train()   # batch statistics, as in a training step
+        outs = []
+        with torch.no_grad():
+            for i in range(0, b, 8):
+                outs.append(gen(partial[i:i + 8])[2].float())
+        del gen
+        _UNTRAINED_CACHE[key] = (torch.cat(outs).contiguous(), gtd)
+    return _UNTRAINED_CACHE[key]
+
+
 def make_network_step(dev, cfg, state, overlap=None):
     """One rank's share of BASELINE config 4 (reconstruction step, 4 clouds) or config 5 (GAN step, 8 clouds) at the
     stated sizes, as a callable: forward + backward + optimiser step(s).  state: `random_init` (the decoder's output

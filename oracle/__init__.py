@@ -198,6 +198,20 @@ def p2i_max_backward(out_grad, out_ids, points, feat, radius):
     return gp, gf, gb
 
 
+def p2i_max_backward_exact(out_grad, out_ids, points, feat, radius):
+    """(points_grad, feat_grad): the fp32 terms of p2i_max_backward summed exactly (in double), rounded once."""
+    og, pg = _f(out_grad)
+    ids, pi = _i(out_ids)
+    points, pp = _f(points)
+    feat, pf = _f(feat)
+    B, C, H, W = og.shape
+    gp = np.zeros_like(points)
+    gf = np.zeros_like(feat)
+    lib().oracle_p2i_max_backward_exact(pg, pi, pp, pf, points.shape[0], C, B, H, W, ctypes.c_float(radius),
+                                        _pf(gp), _pf(gf))
+    return gp, gf
+
+
 def p2i_sum_forward(points, feat, batch_inds, background, radius):
     points, pp = _f(points)
     feat, pf = _f(feat)

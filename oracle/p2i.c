@@ -17,6 +17,7 @@
  */
 #include "sn_oracle.h"
 #include <math.h>
+#include <stdlib.h>
 #include <stddef.h>
 
 static int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -120,6 +121,42 @@ void oracle_p2i_max_backward(const float *out_grad, const int *out_ids, const fl
     points_grad[pid * 2 + 0] += k * dy;
     points_grad[pid * 2 + 1] += k * dx;
   }
+}
+
+// The same fp32 TERMS as oracle_p2i_max_backward (p2i_max.h:94-143), accumulated without rounding: every term is a
+// float, the sums run in double (exact for < 2^29 terms of comparable size) and are rounded to float once.
+// Test infrastructure: what the reference's sequential fp32 `+=` (above) and any order of fp32 atomics on a GPU
+// both approximate, each within (#terms) 2^-24 sum|terms| -- the tolerance the tests give the fp32 order -- and what
+// the HIP path's 64-bit fixed-point accumulation reproduces to the last bit or two.
+void oracle_p2i_max_backward_exact(const float *out_grad, const int *out_ids, const float *points,
+                                   const float *feat, int npoints, int channels, int batch, int h,
+                                   int w, float radius, float *points_grad, float *feat_grad) {
+  double *pg = (double *)calloc((size_t)npoints * 2, sizeof(double));
+  double *fg = (double *)calloc((size_t)npoints * channels, sizeof(double));
+  const size_t total = (size_t)batch * channels * h * w;
+  for (size_t index = 0; index < total; ++index) {
+    const int x = (int)(index % w), y = (int)((index / w) % h);
+    const int c = (int)((index / ((size_t)w * h)) % channels);
+    const float g = out_grad[index];
+    const int pid = out_ids[index];
+    if (pid < 0) continue;
+    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+    const float dx = x - px, dy = y - py;
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float wgt = cos_weight(r, radius);
+    const float fv = feat[pid * channels + c];
+    fg[pid * channels + c] += (double)(float)(g * wgt);
+    const float wg = g * fv;
+    const float rm = r > 1e-10f ? r : 1e-10f;
+    const float k = (float)((double)wg * sin((double)r * M_PI / (double)radius) * 0.5 * M_PI /
+                            (double)radius / (double)rm);
+    pg[pid * 2 + 0] += (double)(float)(k * dy);
+    pg[pid * 2 + 1] += (double)(float)(k * dx);
+  }
+  for (int i = 0; i < npoints * 2; ++i) points_grad[i] = (float)pg[i];
+  for (int i = 0; i < npoints * channels; ++i) feat_grad[i] = (float)fg[i];
+  free(pg);
+  free(fg);
 }
 
 void oracle_p2i_sum_forward(const float *points, const float *feat, const int *batch_inds,

@@ -96,6 +96,11 @@ void oracle_p2i_max_backward(const float *out_grad, const int *out_ids,
                              int npoints, int channels, int batch, int h,
                              int w, float radius, float *points_grad,
                              float *feat_grad, float *background_grad);
+void oracle_p2i_max_backward_exact(const float *out_grad, const int *out_ids,
+                             const float *points, const float *feat,
+                             int npoints, int channels, int batch, int h,
+                             int w, float radius, float *points_grad,
+                             float *feat_grad);
 void oracle_p2i_sum_forward(const float *points, const float *feat,
                             const int *batch_inds, int npoints, int channels,
                             int batch, int h, int w, float radius, float *out);

@@ -78,28 +78,39 @@ void nn_block(const float *q, int q0, int q1, const float *t, int m, float *dist
   }
 }
 
+// An explicit `threads` argument wins; SN_HOST_THREADS only replaces the default (all hardware threads).  Never more
+// threads than items, and few items are not worth a thread each (a thread start costs more than a query block).
 int thread_count(int asked, long items) {
-  int t = asked > 0 ? asked : (int)std::thread::hardware_concurrency();
-  if (const char *e = getenv("SN_HOST_THREADS")) t = atoi(e);
+  int t = asked;
+  if (t <= 0) {
+    const char *e = getenv("SN_HOST_THREADS");
+    t = e ? atoi(e) : (int)std::thread::hardware_concurrency();
+    if (items < 4L * t) t = (int)(items / 4);  // default only: at least four items per thread
+  }
   t = t < 1 ? 1 : (t > 256 ? 256 : t);
   return (long)t > items ? (int)items : t;
 }
 
+// Items are handed out through a counter, so ANY number of workers finishes the job: a thread that cannot be started
+// (std::system_error: EAGAIN under a container's pid limit or inside a DataLoader worker) is simply absent and the
+// calling thread takes items itself -- nothing escapes the extern "C" entry points.
 template <class F>
 void parallel_items(long items, int threads, F fn) {
   if (items <= 0) return;
   const int nt = thread_count(threads, items);
-  if (nt <= 1) {
-    for (long i = 0; i < items; ++i) fn(i);
-    return;
-  }
   std::atomic<long> next{0};
+  auto work = [&] {
+    for (long i = next.fetch_add(1); i < items; i = next.fetch_add(1)) fn(i);
+  };
   std::vector<std::thread> pool;
-  pool.reserve(nt);
-  for (int w = 0; w < nt; ++w)
-    pool.emplace_back([&] {
-      for (long i = next.fetch_add(1); i < items; i = next.fetch_add(1)) fn(i);
-    });
+  if (nt > 1) {
+    try {
+      pool.reserve(nt - 1);
+      for (int w = 0; w + 1 < nt; ++w) pool.emplace_back(work);
+    } catch (...) {  // run with the threads that did start
+    }
+  }
+  work();
   for (auto &th : pool) th.join();
 }
 

@@ -94,7 +94,8 @@ int check_sticky(int dev, const char *what) {
     return fail(SN_ETIMEDOUT,
                 "%s: a bounded wait inside an EARLIER multi-workgroup launch on this device timed out (persistent EMD "
                 "auction or density sampler; the device is shared, or a debugger holds a compute unit); that call's "
-                "outputs were filled with NaN / -1 (EMD) or left incomplete (sampler)", what);
+                "outputs were filled with NaN distances / -1 assignments (EMD) or whole index rows of -1 (sampler; "
+                "sn_gather_forward turns those into NaN features)", what);
   }
   return 0;
 }

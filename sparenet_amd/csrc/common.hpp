@@ -88,16 +88,27 @@ inline bool capturing(hipStream_t s) {
   return yes;
 }
 
-// SN_ALLOW_CAPTURE=1 (debugging, tools/capture_probe.py): the refusals below are lifted
+// SN_ALLOW_CAPTURE=1 lifts the refusals below -- for graphs built with the HIP graph API, where every call of the
+// step replays bit-identically (tools/probe/graph_emd.hip, tests/test_graph_capture.py).  NOT for
+// torch.cuda.CUDAGraph: under PyTorch 2.10 / ROCm 7.2 the auction's second replay hangs and Chamfer forward +
+// backward through autograd faults; a one-time warning on stderr says so.
 inline bool capture_allowed() {
-  static const bool on = [] { const char *e = getenv("SN_ALLOW_CAPTURE"); return e && e[0] == '1'; }();
+  static const bool on = [] {
+    const char *e = getenv("SN_ALLOW_CAPTURE");
+    const bool v = e && e[0] == '1';
+    if (v)
+      fprintf(stderr, "sparenet_hip: SN_ALLOW_CAPTURE=1 -- graph capture of the auction / sorted Chamfer is allowed. Supported "
+                      "for HIP-level graphs (hipGraphLaunch) only: replays under torch.cuda.CUDAGraph hang or fault.\n");
+    return v;
+  }();
   return on;
 }
 
-// Ops that were found NOT to replay correctly from a HIP graph on ROCm 7.2 / gfx950 (tools/graph_probe.py: the
-// persistent auction's replay runs into its barrier time-outs, the Chamfer kernels' replay dies with a memory access
-// fault although the same launches are clean in eager mode with every input at the end of its allocation,
-// tools/oob_probe.py) refuse to be captured instead of producing a graph that misbehaves later.
+// Refused by default because torch is how a user would capture: through the raw HIP graph API these ops replay
+// correctly (section 1 of DESIGN.md), under torch.cuda.CUDAGraph (PyTorch 2.10 on ROCm 7.2 / gfx950) the persistent
+// auction's second replay runs into its barrier time-outs and the Chamfer kernels' replay through autograd dies with a
+// memory access fault, although the same launches are clean in eager mode with every input at the end of its
+// allocation (tools/oob_probe.py).  They refuse instead of producing a graph that misbehaves later.
 #define SN_REFUSE_CAPTURE(stream, what)                                                                     \
   SN_REQUIRE(!sn::capturing(stream) || sn::capture_allowed(), what ": the stream is being captured into a HIP graph; this op does not " \
                                            "replay correctly from a graph (see common.hpp) -- launch it eagerly")

@@ -158,6 +158,15 @@ __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
     __hip_atomic_fetch_min(reinterpret_cast<unsigned *>(addr), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// the same, returning the value the word held before (NaN-free inputs; -1e9 and 0 are the only other values stored)
+__device__ __forceinline__ float atomic_max_float_old(float *addr, float v) {
+  if (v >= 0.f)
+    return __int_as_float(__hip_atomic_fetch_max(reinterpret_cast<int *>(addr), __float_as_int(v), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT));
+  return __uint_as_float(__hip_atomic_fetch_min(reinterpret_cast<unsigned *>(addr), __float_as_uint(v), __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // ---- coherent accesses for data that workgroups hand to each other INSIDE the persistent launch.
 // A relaxed agent-scope atomic load / store is a plain global_load / global_store with the sc1 bit: it
 // bypasses the per-CU vector L1 (never refreshed by other CUs' stores) and is coherent across the XCDs'
@@ -192,6 +201,15 @@ __device__ __forceinline__ void stc2(bool loc, int *p, int x, int y) {  // 8-byt
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stc64(bool loc, unsigned long long *p, unsigned long long v) {
+  if (loc)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long ldc64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // {price, target index} of a stream position: ONE coherent 8-byte load (the price changes inside the launch)
 __device__ __forceinline__ float2 ldc_pk(const float2 *p) {
@@ -331,11 +349,116 @@ __global__ __launch_bounds__(256) void emd_sbbox_kernel(int B, int n, const floa
 
 // First-iteration seeds.  The bid filter needs, per bidder, two real targets whose values
 // bound the final `better` from below; later iterations use the previous favourites, the first
-// one has none and would evaluate ~75 targets per bidder exactly before its thresholds
-// tighten.  Targets are already in Morton order: a window of 16 sorted positions around the
-// bidder's own cell supplies candidates, the two nearest become bid/bid2.  ANY two distinct
-// targets are valid seeds; better ones only make the filter reject more.
-__global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
+// one has none.  ANY two distinct targets are valid seeds; better ones only make the filter reject more --
+// and how much more depends on the data: a window of the targets' Morton order around the bidder's own cell
+// (rounds 1-4, emd_seed_window_kernel below) finds near neighbours when the two clouds fill the same volume,
+// but for a prediction that lies OFF the targets' surface (early training: scattered around it, or the refine
+// stages of an untrained generator) the bidder's cell holds no target and its stream neighbours can be anywhere:
+// the first iteration of the scattered probe took 670 us of a 2.6 ms call at 4 clouds, the workgroups with the far
+// bidders 3x the average (profiles/r05_a_emd_regimes_before.txt).  emd_seed_kernel walks the box hierarchy the bid
+// phase uses anyway -- the 64 groups of 256 targets, then the 16-target blocks of the two nearest groups -- and takes
+// the two nearest targets of the two nearest blocks: ~130 box / point tests per bidder whatever the data.
+constexpr int kSeedThreads = 256;
+constexpr int kSeedBlk = 1024;  // blocks of 16 targets whose boxes fit the kernel's LDS (n <= 16384), as in bid_scan
+
+__device__ __forceinline__ float box_gap2(const f4 A, const f4 B, float x, float y, float z) {
+  const float gx = __builtin_fmaxf(__builtin_fmaxf(A.x - x, x - A.w), 0.f);
+  const float gy = __builtin_fmaxf(__builtin_fmaxf(A.y - y, y - B.x), 0.f);
+  const float gz = __builtin_fmaxf(__builtin_fmaxf(A.z - z, z - B.y), 0.f);
+  return (gx * gx + gy * gy) + gz * gz;
+}
+
+__global__ __launch_bounds__(kSeedThreads) void emd_seed_kernel(int B, int n, const float *__restrict__ xyz1,
+                                                                EmdWs ws) {
+#pragma clang fp contract(off)
+  __shared__ f4 s_blk[kSeedBlk][2];
+  __shared__ f4 s_hb[kSeedBlk / 16][2];
+  const int per = n / kSeedThreads;           // workgroups per cloud (n % 1024 == 0)
+  const int bb = blockIdx.x / per;
+  const int r = (blockIdx.x - bb * per) * kSeedThreads + threadIdx.x;  // the bidder's Hilbert rank: neighbours share blocks
+  const int nblk = n >> 4, nh = n >> 8;
+  {
+    const f4 *src = reinterpret_cast<const f4 *>(ws.sbbox + (size_t)bb * nblk * 8);
+    f4 *dst = &s_blk[0][0];
+    for (int i = threadIdx.x; i < 2 * nblk; i += kSeedThreads) dst[i] = src[i];
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < nh; h += kSeedThreads) {
+    f4 lo = s_blk[16 * h][0], hi = s_blk[16 * h][1];
+    for (int q = 1; q < 16; ++q) {
+      const f4 l2 = s_blk[16 * h + q][0], h2 = s_blk[16 * h + q][1];
+      lo.x = __builtin_fminf(lo.x, l2.x);
+      lo.y = __builtin_fminf(lo.y, l2.y);
+      lo.z = __builtin_fminf(lo.z, l2.z);
+      lo.w = __builtin_fmaxf(lo.w, l2.w);
+      hi.x = __builtin_fmaxf(hi.x, h2.x);
+      hi.y = __builtin_fmaxf(hi.y, h2.y);
+    }
+    s_hb[h][0] = lo;
+    s_hb[h][1] = hi;
+  }
+  __syncthreads();
+  const size_t o = (size_t)bb * n;
+  const int j = ws.perm1[o + r];
+  const float x = xyz1[(o + j) * 3 + 0], y = xyz1[(o + j) * 3 + 1], z = xyz1[(o + j) * 3 + 2];
+  // the two nearest groups of 256 targets (by box distance), then the two nearest blocks among their 32
+  float g1 = 3e38f, g2 = 3e38f;
+  int h1 = 0, h2 = 0;
+  for (int h = 0; h < nh; ++h) {
+    const float g = box_gap2(s_hb[h][0], s_hb[h][1], x, y, z);
+    if (g < g1) {
+      g2 = g1;
+      h2 = h1;
+      g1 = g;
+      h1 = h;
+    } else if (g < g2) {
+      g2 = g;
+      h2 = h;
+    }
+  }
+  if (nh < 2) h2 = h1;
+  float c1 = 3e38f, c2 = 3e38f;
+  int b1 = 16 * h1, b2 = 16 * h1 + 1;
+  for (int t = 0; t < (h2 == h1 ? 16 : 32); ++t) {
+    const int blk = (t < 16 ? 16 * h1 : 16 * h2 - 16) + t;
+    const float g = box_gap2(s_blk[blk][0], s_blk[blk][1], x, y, z);
+    if (g < c1) {
+      c2 = c1;
+      b2 = b1;
+      c1 = g;
+      b1 = blk;
+    } else if (g < c2) {
+      c2 = g;
+      b2 = blk;
+    }
+  }
+  float s1 = 3e38f, s2 = 3e38f;
+  int k1 = -1, k2 = -1;
+  for (int t = 0; t < 32; ++t) {  // the prepared stream: one 16-byte record per position
+    const f4 tg = ws.t4s[o + 16 * (t < 16 ? b1 : b2) + (t & 15)];
+    const int k = __float_as_int(tg.w);
+    const float dx = tg.x - x, dy = tg.y - y, dz = tg.z - z;
+    const float sq = (dx * dx + dy * dy) + dz * dz;
+    if (sq < s1) {
+      s2 = s1;
+      k2 = k1;
+      s1 = sq;
+      k1 = k;
+    } else if (sq < s2) {
+      s2 = sq;
+      k2 = k;
+    }
+  }
+  ws.bid[o + j] = k1;
+  ws.bid2[o + j] = k2;
+  // the reference's max_idx tensor starts as zeros = "bidder 0" (emd_module.py:50); kept here as a RANK
+  ws.max_idx[o + r] = ws.rank1[o];
+}
+
+// The window form (clouds whose block boxes do not fit the LDS copy, n > 16384): targets are already in Morton
+// order; a window of 16 sorted positions around the bidder's own cell supplies candidates, the two nearest
+// become bid / bid2.
+__global__ __launch_bounds__(kThreads) void emd_seed_window_kernel(int B, int n,
                                                             const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2,
                                                             EmdWs ws) {
@@ -390,6 +513,12 @@ struct BidOut {
   float *max_inc;
   int *head;
   bool loc;  // the team sits on one XCD: plain stores (see stc)
+  // outbid-skip (see emit_bid): 0 = off, else the bidder re-flags itself through these
+  int skip;
+  int *flags;    // [n] of this cloud, by rank
+  int *s_bins;   // LDS counters of re-flagged bidders per rank bin
+  int binsize;
+  int *s_skipped;  // LDS: bidders this workgroup re-flagged on arrival in this iteration
 };
 
 #ifndef SN_EMD_BIDWAVES
@@ -406,32 +535,62 @@ constexpr int kStash = kBidThreads;  // list slots whose bid is handed to the aw
 
 // What the award phase needs to know about the bid of list slot u (written by the wave that emits the bid, read
 // after the team barrier by thread u): saves the llist -> bid -> rec chain of dependent coherent loads.
+// next == kStashOpen: the slot's bid was NOT emitted by this workgroup (another workgroup of the team took the
+// bidder over, see "work hand-off" in the kernel): the award phase reads the record from global memory.
+// tgt == kStashDone: the bidder re-flagged itself in the bid phase (outbid on arrival): nothing left to do.
 struct BidStash {
   int tgt, rank, inc_bits, next;
 };
+constexpr int kStashOpen = -2, kStashDone = -2;
 
 // The bid of bidder j (Morton rank `rank`, list slot u).  Besides the favourites (next iteration's filter seeds)
 // and the running maximum of the target's increments (emd_cuda.cu:175-177), the bidder LINKS itself into the
 // list of its target: head[target] <- rank, rec[rank] = {increment, previous head}.  After the team barrier the
 // bidder that finds itself at the head walks the list (award phase of the kernel).
-__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int rank, int u, BidStash *stash,
-                                         const Top2 &top, float eps) {
+//
+// Outbid on arrival (A.skip).  GetMax's winner lies inside the window |inc - mi| <= 1e-6 around the FINAL maximum mi
+// of the target's increments (emd_cuda.cu:188), and the running maximum only grows inside an iteration: a bidder
+// that finds the word already above inc + 1e-6 (the reference's double compare) can never be inside the window,
+// whatever arrives later.  For eps >= 0 somebody always IS inside it (the bidder that sets the maximum; the word
+// starts at 0 <= every increment), so the persistent max_idx entry never decides and such a bidder simply stays
+// unassigned (emd_cuda.cu:200: neither forced nor the winner): it re-flags itself here and does not enter the
+// list.  With L bidders on one target arriving in random order ~ln L of them link themselves: on the refine stages
+// of an untrained generator (hundreds of far bidders on every near target: lists of 200-480, walked by ONE thread
+// at a dependent load per entry) 7000 bidders leave 1400 list entries, the longest list 10
+// (tools/sim/auction_regime_stats.c).  Costs one more dependent round trip per bid (the maximum must RETURN the old
+// value before the exchange), so it is switched on per iteration by the lists the award phase walked in the
+// previous one (the team's `cont` word).  Never in the last iteration (every bidder takes its target there) and
+// never for eps < 0.
+__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int rank, int u, bool local,
+                                         BidStash *stash, const Top2 &top, float eps) {
   const bool loc = A.loc;
+  const bool st = local && u < kStash;
   if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
     stc(loc, &A.bid[o + j], -1);
     stc(loc, &A.bid2[o + j], -1);
     stc2(loc, &A.rec[2 * (o + rank)], 0, -1);
-    if (u < kStash) stash[u] = BidStash{-1, rank, 0, -1};
+    if (st) stash[u] = BidStash{-1, rank, 0, -1};
     return;
   }
   const float inc = (top.best - top.better) + eps;
   stc(loc, &A.bid[o + j], top.best_i);
   stc(loc, &A.bid2[o + j], top.better_i == top.best_i ? -1 : top.better_i);
-  atomic_max_float(&A.max_inc[o + top.best_i], inc);
+  if (A.skip) {
+    const float before = atomic_max_float_old(&A.max_inc[o + top.best_i], inc);
+    if ((double)before > (double)inc + 1e-6) {  // outbid already: stays unassigned, bids again
+      stc(loc, &A.flags[rank], 1);
+      atomicAdd(&A.s_bins[rank / A.binsize], 1);
+      atomicAdd(A.s_skipped, 1);
+      if (st) stash[u] = BidStash{kStashDone, rank, 0, -1};
+      return;
+    }
+  } else {
+    atomic_max_float(&A.max_inc[o + top.best_i], inc);
+  }
   const int prev = (int)__hip_atomic_exchange(reinterpret_cast<unsigned *>(&A.head[o + top.best_i]), (unsigned)rank,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   stc2(loc, &A.rec[2 * (o + rank)], __float_as_int(inc), prev);
-  if (u < kStash) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), prev};
+  if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), prev};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -550,6 +709,34 @@ struct AuctionCtl {  // zeroed by a memset node before every launch
   unsigned bar[1];  // [teams * 32]: one counter per team, 128 bytes apart
 };
 
+// Work hand-off inside a team (one block per team, zeroed by a memset node before every launch).
+// The ranks are split by bidder COUNT; what a bidder costs depends on the data -- on clouds scattered around a
+// surface a bidder's reach holds 25 blocks on average and up to 330 (tools/sim/auction_regime_stats.c) -- and on
+// such data the team waited at the first barrier of every iteration for the workgroup that happened to own the
+// expensive bidders: 1.25 of a 2.6 ms call at 4 clouds, 16.5 of 79 ms on the refine stages of an untrained
+// generator at 32 (profiles/r05_a_emd_regimes_before.txt).  A workgroup whose list holds more than one chunk per
+// wave (scan: 4 bidders; matrix-core search: a group of 64) PUBLISHES it -- {stamp, count, first rank} in one 64-bit
+// word, after its list has reached the L2 -- and its waves take chunks beyond the first kBidWaves from a cursor
+// instead of a fixed stride; a wave of ANOTHER workgroup of the team that has run out of work reads the team's
+// words, picks the workgroup with most chunks left, and takes chunks from the same cursor (bid_scan / bid_group with
+// local == false: the list entry is read from global memory, the bid reaches the award phase through global memory;
+// the owner's award phase finds the slot's stash still open).  Which wave serves a bidder never enters a result.
+// Nobody waits for anybody: an unpublished word (stale stamp) is skipped.  Not in the fenced fallback mode.
+struct TeamSteal {
+  unsigned long long pub[2][32];  // [iteration parity][member]: stamp : 24 | bidders : 20 | first rank : 20
+  unsigned cur[2][32];            // [iteration parity][member]: chunks taken beyond the static first kBidWaves
+  unsigned cont[2];               // [iteration parity]: stamp of the iteration that should skip outbid bidders (emit_bid)
+  unsigned pad[62];
+};
+static_assert(sizeof(TeamSteal) == 1024, "TeamSteal");
+// Looking costs every wave two coherent loads and a reduction (~2.5 us): only a workgroup that polled the previous
+// first barrier at least this often (~10 us; balanced teams wait 3-5) looks for work, and only while the team has
+// enough bidders for anybody to have published a list.  Always-look cost 0.33 ms of a 2.0 ms call on uniform clouds.
+#ifndef SN_EMD_STEAL_POLLS
+#define SN_EMD_STEAL_POLLS 14
+#endif
+constexpr int kStealWaitPolls = SN_EMD_STEAL_POLLS;
+
 struct TeamGeom {
   int G;       // workgroups per team (power of two)
   int teams;   // teams in the launch
@@ -610,7 +797,10 @@ struct TeamSync {
 // L1, sc1 accesses meeting in the L2 / at the fabric), which the HIP memory model does not promise: the library
 // verifies it once per device with a litmus kernel (emd_litmus_kernel) and falls back to `fenced` barriers +
 // agent-scope stores when the check fails or SN_EMD_SAFE=1 is set.
-__device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
+// s_wait (optional, LDS): how long this workgroup waited for the others, in polls of the counter (~0.7 us each: a
+// sleep + one coherent load) -- the work hand-off's signal that the team is out of balance.  (Not the realtime
+// clock: two s_memrealtime reads cost 0.5 us of every barrier.)
+__device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag, int *s_wait = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
@@ -632,6 +822,7 @@ __device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
       }
     }
     *s_flag = ok;
+    if (s_wait) *s_wait = (int)spins;
   }
   __syncthreads();
   if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -660,8 +851,11 @@ struct BidCtx {
 };
 
 // One group of 64 bidders, seen by one of its S segment-waves.
+// S == 1: the wave serves the group alone (its GroupAcc slot is private, no workgroup barrier inside): the form in
+// which a wave takes groups over -- from its own workgroup's cursor or from another workgroup of the team
+// (local == false: `lst` / `count` are that workgroup's list, the bid goes to the award phase through global memory).
 __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc &ga, const int *lst,
-                                          int count, int grp, int ngroups, int S, int seg, int lane) {
+                                          int count, int grp, int ngroups, int S, int seg, int lane, bool local) {
   const int row = lane >> 4, col = lane & 15;
   const int u = grp * 64 + lane;
   const bool active = grp < ngroups && u < count;
@@ -700,7 +894,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
     ga.sj[lane] = jj;
     ga.sr[lane] = jr.y;
   }
-  __syncthreads();  // every wave of the workgroup calls bid_group the same number of times
+  if (S > 1) __syncthreads();  // every wave of the workgroup calls bid_group the same number of times
   if (grp < ngroups) {  // wave-uniform
     j = ga.sj[lane];
     float blo[4][3], bhi[4][3];
@@ -991,7 +1185,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       atomicExch(&ga.lock, 0);
     }
   }
-  if (emit && active) emit_bid(c.A, c.o, j, ga.sr[lane], u, c.stash, top, c.eps);
+  if (emit && active) emit_bid(c.A, c.o, j, ga.sr[lane], u, local, c.stash, top, c.eps);
 #ifdef SN_BID_STAMPS
   STAMP(4)
   if (c.stamps && lane == 0)
@@ -1031,6 +1225,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
 #define SN_EMD_SCAN_MAX 384  // bidders per workgroup up to which an iteration takes bid_scan (SN_EMD_SCAN overrides;
                              // 128 / 256 / 384 / 512 / 1024: 2.24 / 2.10 / 2.07 / 2.07 / 2.08 ms per call at 32 clouds, r04)
 #endif
+constexpr int kScanContested = 4096;  // bidders per workgroup up to which a CONTESTED iteration takes bid_scan (see the kernel)
 constexpr int kScanBlk = 1024;  // blocks of 16 targets whose boxes fit in the LDS copy (n <= 16384)
 constexpr int kScanList = 64;   // blocks within reach a quarter wave lists before it evaluates them
 
@@ -1050,6 +1245,9 @@ __device__ __forceinline__ bool box_within(const f4 A, const f4 B, float x, floa
 #define SN_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
 #define SN_DPP_I(v, ctrl) __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true)
 
+#ifndef SN_SCAN_RESHARE
+#define SN_SCAN_RESHARE 0  // > 0: the lanes share their bound again every that many rounds (see bid_scan)
+#endif
 constexpr int kRoundC = 4;  // blocks per round (two rounds are in flight: the register budget decides)
 struct ScanCand {  // one round of a quarter wave: lane c holds target c of each of the round's blocks
   f4 t[kRoundC];     // {x, y, z, index bits}
@@ -1057,8 +1255,23 @@ struct ScanCand {  // one round of a quarter wave: lane c holds target c of each
 };
 
 
-__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int wave,
-                                         int lane) {
+// A workgroup's `count` bidders are served in PASSES of kQuarters quarter waves; T = 1 / 2 / 4 quarters share a
+// bidder in a pass that has at most kQuarters / T bidders left (only the last pass can).  A CHUNK is one wave's
+// share of a pass -- 4 / T bidders -- and the unit in which waves take work: chunk c = pass c / kBidWaves, wave
+// slot c % kBidWaves.  scan_chunks(count) = the number of chunks that hold a bidder.
+constexpr int kQuarters = kBidWaves * 4;  // quarter waves of a workgroup
+__device__ __forceinline__ int scan_tsh(int rem) { return rem <= kQuarters / 4 ? 2 : (rem <= kQuarters / 2 ? 1 : 0); }
+__device__ __forceinline__ int scan_chunks(int count) {
+  if (count <= 0) return 0;
+  const int full = (count - 1) / kQuarters;        // passes before the last one: kQuarters bidders each
+  const int rem = count - full * kQuarters;        // 1 .. kQuarters
+  return full * kBidWaves + (((rem << scan_tsh(rem)) + 3) >> 2);
+}
+
+// `wave`: the EXECUTING wave (its LDS list); `chunk`: which bidders; local: the list is this workgroup's own (the
+// entries wait in the stash, the bid is handed to the award phase through it).
+__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int chunk,
+                                         bool local, int wave, int lane) {
   const int row = lane >> 4, col = lane & 15;
   const int nh = c.nsb >> 2;  // groups of 16 blocks
   const int nblk = c.nsb << 2;
@@ -1077,12 +1290,10 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
 #define STAMP(i)
 #define COUNT(i, v)
 #endif
-  for (int u0 = 0; u0 < count;) {
-    // T quarter waves per bidder: with few bidders left a bidder's superblocks are dealt out to 2 or 4 quarters
-    const int rem = count - u0;
-    constexpr int kQuarters = kBidWaves * 4;  // quarter waves of the workgroup (qd below runs over them)
-    const int tsh = rem <= kQuarters / 4 ? 2 : (rem <= kQuarters / 2 ? 1 : 0), T = 1 << tsh;  // uniform in the workgroup
-    const int qd = wave * 4 + row;
+  {
+    const int u0 = (chunk / kBidWaves) * kQuarters;
+    const int tsh = scan_tsh(count - u0), T = 1 << tsh;  // uniform in the pass
+    const int qd = (chunk % kBidWaves) * 4 + row;
     const int u = u0 + (qd >> tsh), part = qd & (T - 1);
     const bool active = u < count;  // uniform within the quarter
     int jj = 0, rank = 0, ba = -1, bb = -1;  // ba, bb: the blocks of the two previous favourites
@@ -1091,7 +1302,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       // two round trips: {coordinates, previous favourites} of the bidder, then the favourites' coordinates and
       // prices BY INDEX (the caller's array and the price array of the award phase; their stream positions, needed
       // for the lists only, arrive beside them)
-      if (u < kStash) {  // left there by the compaction
+      if (local && u < kStash) {  // left there by the compaction
         jj = c.stash[u].tgt;
         rank = c.stash[u].rank;
       } else {
@@ -1172,6 +1383,27 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
         }
       }
     };
+    // the lanes (and the quarters that share the bidder) hold disjoint targets: the second largest value any of them
+    // has seen bounds the final `better` from below
+    auto share = [&]() {
+      float m1 = top.best, m2 = top.better;
+#define SN_SHARE_STEP(o1_, o2_)                                                  \
+      {                                                                          \
+        const float o1 = o1_, o2 = o2_;                                          \
+        m2 = __builtin_fmaxf(__builtin_fminf(m1, o1), __builtin_fmaxf(m2, o2)); \
+        m1 = __builtin_fmaxf(m1, o1);                                            \
+      }
+      SN_SHARE_STEP(SN_DPP_F(m1, 0xB1), SN_DPP_F(m2, 0xB1))
+      SN_SHARE_STEP(SN_DPP_F(m1, 0x4E), SN_DPP_F(m2, 0x4E))
+      SN_SHARE_STEP(SN_DPP_F(m1, 0x141), SN_DPP_F(m2, 0x141))
+      SN_SHARE_STEP(SN_DPP_F(m1, 0x140), SN_DPP_F(m2, 0x140))
+      for (int d = 16; d < 16 * T; d <<= 1) SN_SHARE_STEP(__shfl_xor(m1, d), __shfl_xor(m2, d))
+#undef SN_SHARE_STEP
+      qlb = __builtin_fmaxf(qlb, m2);
+    };
+#if SN_SCAN_RESHARE > 0
+    int rounds = 0;
+#endif
     do {
       // The blocks within reach into the lists of the team's quarters, dealt out in turn.  The blocks of the two
       // previous favourites go first: after the round that holds them the team knows two values near the final
@@ -1223,26 +1455,19 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
           process(A, i, cnt);
           if (first) {  // uniform: the first round of the bidder
             first = false;
-            float m1 = top.best, m2 = top.better;
-#define SN_SHARE_STEP(o1_, o2_)                                                  \
-            {                                                                    \
-              const float o1 = o1_, o2 = o2_;                                    \
-              m2 = __builtin_fmaxf(__builtin_fminf(m1, o1), __builtin_fmaxf(m2, o2)); \
-              m1 = __builtin_fmaxf(m1, o1);                                      \
-            }
-            SN_SHARE_STEP(SN_DPP_F(m1, 0xB1), SN_DPP_F(m2, 0xB1))
-            SN_SHARE_STEP(SN_DPP_F(m1, 0x4E), SN_DPP_F(m2, 0x4E))
-            SN_SHARE_STEP(SN_DPP_F(m1, 0x141), SN_DPP_F(m2, 0x141))
-            SN_SHARE_STEP(SN_DPP_F(m1, 0x140), SN_DPP_F(m2, 0x140))
-            for (int d = 16; d < 16 * T; d <<= 1) SN_SHARE_STEP(__shfl_xor(m1, d), __shfl_xor(m2, d))
-#undef SN_SHARE_STEP
-            qlb = m2;  // lanes and quarters hold disjoint targets: the second largest value seen bounds the final `better`
+            share();
           }
+#if SN_SCAN_RESHARE > 0
+          else if ((++rounds % SN_SCAN_RESHARE) == 0) share();
+#endif
           i += kRoundC;
           if (!more) break;
           const bool more2 = __any(i + kRoundC < cnt);
           if (more2) fetch(A, i + kRoundC, cnt);
           process(B, i, cnt);
+#if SN_SCAN_RESHARE > 0
+          if ((++rounds % SN_SCAN_RESHARE) == 0) share();
+#endif
           i += kRoundC;
           if (!more2) break;
         }
@@ -1268,9 +1493,8 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       const int oi = __shfl_xor(top.best_i, d), oi2 = __shfl_xor(top.better_i, d);
       top2_merge(top, ob, obb, oi, oi2, geom);
     }
-    if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, c.stash, top, c.eps);
+    if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, local, c.stash, top, c.eps);
     STAMP(4)
-    u0 += kQuarters >> tsh;
   }
 #ifdef SN_BID_STAMPS
   if (c.stamps && lane == 0)
@@ -1301,6 +1525,9 @@ struct AuctionArgs {
   long long *dwords;
   int scan_max;  // iterations with at most this many bidders in the workgroup take bid_scan (0: never)
   int prof;      // 1: record the execution window in the control block (sn_prof_enable)
+  TeamSteal *steal;  // one block per team
+  int steal_mode;    // work hand-off: 0 never, 1 when the previous first barrier made this workgroup wait (default), 2 always look
+  int skip_mode;     // outbid-skip: 0 never, 1 after an iteration with long lists (default), 2 always
 };
 
 // The kernel's LDS, carved from the DYNAMIC segment on purpose: with a static 101 KB the compiler derives "one
@@ -1314,7 +1541,8 @@ struct AuctionLds {
   GroupAcc gacc[kBidWaves];
   BidStash stash[kStash];
   int wsum[kBidWaves];
-  int s_flag, s_ticket, s_stray, s_range[3], s_bins[kRankBins];
+  int s_flag, s_ticket, s_stray, s_range[4], s_bins[kRankBins];
+  int s_wait, s_long, s_skipped;
   ScanLds scan;
 };
 
@@ -1331,6 +1559,11 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   int *wsum = L.wsum;
   int &s_flag = L.s_flag, &s_ticket = L.s_ticket, &s_stray = L.s_stray;
   int *s_range = L.s_range, *s_bins = L.s_bins;
+  if (threadIdx.x == 0) {
+    L.s_wait = 1 << 30;  // no history yet: the first iteration looks for work
+    L.s_long = 0;
+    L.s_skipped = 0;
+  }
 #ifdef SN_EMD_PRIO
   __builtin_amdgcn_s_setprio(SN_EMD_PRIO);  // the chain of dependent steps goes first; co-resident waves fill the gaps
 #endif
@@ -1421,7 +1654,14 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   float *price = a.ws.price;
   int *flags = a.ws.flags;
   int *llist_all = a.ws.list[0];
-  const BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc};
+  BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc, 0, nullptr, s_bins, binsize, &L.s_skipped};
+  // work hand-off / outbid-skip state of this team (TeamSteal); XCD-geometry teams only (they have a formation barrier)
+#ifdef SN_EMD_NOSTEAL   // experiment builds: the hand-off compiled out
+  TeamSteal *const tsd = nullptr;
+#else
+  TeamSteal *const tsd = (a.steal && a.tg.xcd && G > 1 && G <= 32 && !a.safe) ? a.steal + team : nullptr;
+#endif
+  int cloud_seq = 0;
   if (a.diag && m == 0 && tid == 0 && loc) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + 12, 1ull);  // teams on one XCD
 
   for (int b = team; b < a.B; b += a.tg.teams) {
@@ -1447,9 +1687,19 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
     c.rk2 = a.ws.rank2 + o;
     c.ms = a.ws.mstream + (size_t)b * nsb * 64;
     c.sbb = a.ws.sbbox + (size_t)b * nsb * 32;
+    bo.flags = flags + o;
     c.A = bo;
     c.stash = stash;
     const int *perm1 = a.ws.perm1 + o;
+    // stamps grow from cloud to cloud and from iteration to iteration: a word left by an earlier cloud or iteration
+    // never looks like this iteration's
+    const unsigned stamp0 = (unsigned)cloud_seq * (unsigned)(a.iters + 1);
+    ++cloud_seq;
+    if (tsd && tid == 0) {  // a cloud that ended early (U == 0) may have left its last cursor used
+      stc(loc, reinterpret_cast<int *>(&tsd->cur[0][m]), 0);
+      stc(loc, reinterpret_cast<int *>(&tsd->cur[1][m]), 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... before this workgroup can publish anything
+    }
     // bid_scan's copy of the cloud's box hierarchy (constant for the whole call)
     const bool scan_ok = a.scan_max > 0 && 4 * nsb <= kScanBlk;  // nsb % 16 == 0 (n % 1024 == 0)
     if (scan_ok) {
@@ -1513,15 +1763,20 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           cnt += __popcll(__ballot(own == m));
           excl += v[q];
         }
+        int contw = 0;
+        if (tsd && lane == 0) contw = ldc(reinterpret_cast<const int *>(&tsd->cont[cur]));
         if (lane == 0) {
           s_range[0] = total;
           s_range[1] = first * binsize;
           s_range[2] = cnt * binsize;
+          s_range[3] = contw;
         }
       }
       __syncthreads();
       const int U = s_range[0], r0 = s_range[1], R = s_range[2];
       if (U == 0) break;  // every workgroup of the team reads the same value
+      const unsigned stamp = (stamp0 + (unsigned)it + 1u) & 0xffffffu;
+      if (tsd && tid == 64) stc(loc, reinterpret_cast<int *>(&tsd->cur[cur ^ 1][m]), 0);  // the next iteration's cursor (last used two barriers ago)
       int *llist = llist_all + 2 * (o + r0);   // {index, rank} pairs
       const bool last = it == a.iters - 1;
       if (m == 0 && tid == 0 && a.stats) {
@@ -1576,6 +1831,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
               if (pos < kStash) {
                 stash[pos].tgt = j;
                 stash[pos].rank = rr;
+                stash[pos].next = kStashOpen;  // until this workgroup emits the slot's bid itself
               }
               ++pos;
             };
@@ -1602,23 +1858,98 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
 #ifdef SN_BID_STAMPS
         c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
 #endif
-        if (scan_ok && Um <= a.scan_max) {  // sparse iteration (uniform in the workgroup): a quarter wave per bidder
-          bid_scan(c, L.scan, llist, Um, wave, lane);
-        } else {
-          const int ngroups = (Um + 63) >> 6;
-          int S = 1;
-          while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
-          const int gpb = kBidWaves / S;
-          const int seg = wave & (S - 1), gslot = wave / S;
-          for (int q0 = 0; q0 < ngroups; q0 += gpb) {
-            bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
-            if (q0 + gpb < ngroups) __syncthreads();
+        // outbid-skip: for eps >= 0, not in the last iteration, when the previous iteration's award phase met long
+        // lists (or skipped many bidders itself: with the skip on the lists are short, so the skip count keeps it on)
+        c.A.skip = (a.eps >= 0.f && !last && (a.skip_mode == 2 || (a.skip_mode == 1 && tsd && (unsigned)s_range[3] == stamp))) ? 1 : 0;
+        // Which bid form.  Sparse bidders go to the scan (SN_EMD_SCAN_MAX); so does EVERY iteration of a contested
+        // auction (the team's `cont` word = c.A.skip, the same for every workgroup of the team): hundreds of far
+        // bidders per near target are the data on which the matrix-core search finds most pairs "near" and pays for
+        // each hit in its queue -- the refine stages of an untrained generator at 32 clouds: 56.7 -> 29.7 ms per call
+        // with the scan throughout, uniform clouds 2.45 -> 2.57 (profiles/r05_a_emd_knobs.txt).
+        const int scan_max = (c.A.skip && a.scan_max > 0 && a.scan_max < kScanContested) ? kScanContested : a.scan_max;
+        const bool scan = scan_ok && Um <= scan_max;  // uniform in the workgroup
+        const int ngroups = (Um + 63) >> 6;
+        int S = 1;
+        while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
+        // Work units ("chunks"): a wave's share of a scan pass, or a group of 64 bidders.  With S > 1 (few groups:
+        // S waves share one, the workgroup walks its groups in step) the schedule is fixed; otherwise a wave serves
+        // chunk `wave` first and takes further ones from the workgroup's cursor -- and, when its own list is done,
+        // from other workgroups of the team (TeamSteal).  ONE call site per bid form: the bodies are large.
+        const bool coop = !scan && S > 1;
+        const int gpb = kBidWaves / S;
+        const int seg = coop ? (wave & (S - 1)) : 0, gslot = coop ? wave / S : wave;
+        const int nchunks = scan ? scan_chunks(Um) : ngroups;
+        const bool shared = !coop && tsd && nchunks > kBidWaves && Um < (1 << 20);  // uniform in the workgroup
+        if (shared) {  // publish the list: every entry must have reached the L2 first
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tid == 0)
+            stc64(loc, &tsd->pub[cur][m],
+                  ((unsigned long long)stamp << 40) | ((unsigned long long)(unsigned)Um << 20) | (unsigned long long)(unsigned)r0);
+        }
+        auto take = [&](unsigned *cursor) {  // the next chunk index beyond the static ones
+          unsigned v = 0;
+          if (lane == 0) v = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return kBidWaves + __builtin_amdgcn_readfirstlane((int)v);
+        };
+        // (a published list holds more than kBidWaves chunks: with U bidders over G workgroups that takes U > ~64 G)
+        const bool look = !coop && tsd && (a.steal_mode == 2 || (a.steal_mode == 1 && L.s_wait > kStealWaitPolls &&
+                                                                  (!scan || 2 * U > kQuarters * G)));
+        // the list being served: this workgroup's own one first
+        const int *w_lst = llist;
+        int w_count = Um, w_n = coop ? ngroups : nchunks;
+        bool w_scan = scan, w_local = true;
+        unsigned *w_cursor = shared ? &tsd->cur[cur][m] : nullptr;
+        int chunk = coop ? gslot : wave;
+        for (;;) {
+          if (coop) {
+            if (chunk - gslot >= ngroups) break;  // q0 = chunk - gslot runs over the rounds: every wave the same number of calls
+          } else if (chunk >= w_n) {
+            if (!look) break;
+            // Another workgroup's list.  Every wave looks on its own: lane l reads member l's words.
+            int left = 0, vcount = 0, vr0 = 0, vn = 0;
+            if (lane < G && lane != m) {
+              const unsigned long long w = ldc64(&tsd->pub[cur][lane]);
+              const int taken = ldc(reinterpret_cast<const int *>(&tsd->cur[cur][lane]));
+              if ((unsigned)(w >> 40) == stamp) {
+                vcount = (int)((w >> 20) & 0xfffffu);
+                vr0 = (int)(w & 0xfffffu);
+                vn = (scan_ok && vcount <= scan_max) ? scan_chunks(vcount) : (vcount + 63) >> 6;
+                left = vn - kBidWaves - taken;
+              }
+            }
+            int key = left > 0 ? (left << 6) | lane : 0;  // the member with most chunks left
+            for (int d = 1; d < 64; d <<= 1) {
+              const int o2 = __shfl_xor(key, d);
+              key = o2 > key ? o2 : key;
+            }
+            key = __builtin_amdgcn_readfirstlane(key);
+            if (key == 0) break;
+            const int v = key & 63;
+            w_count = __builtin_amdgcn_readlane(vcount, v);
+            w_n = __builtin_amdgcn_readlane(vn, v);
+            w_lst = llist_all + 2 * (o + __builtin_amdgcn_readlane(vr0, v));
+            w_scan = scan_ok && w_count <= scan_max;
+            w_local = false;
+            w_cursor = &tsd->cur[cur][v];
+            chunk = take(w_cursor);
+            continue;
+          }
+          if (w_scan)
+            bid_scan(c, L.scan, w_lst, w_count, chunk, w_local, wave, lane);
+          else
+            bid_group(c, tabs[wave], gacc[gslot], w_lst, w_count, chunk, (w_count + 63) >> 6, coop ? S : 1, seg, lane, w_local);
+          if (coop) {
+            chunk += gpb;
+            if (chunk - gslot < ngroups) __syncthreads();
+          } else {
+            chunk = w_cursor ? take(w_cursor) : chunk + kBidWaves;
           }
         }
       }
       if (a.diag) __syncthreads();
       tick(6);
-      if (!team_barrier(ts, &s_flag)) {
+      if (!team_barrier(ts, &s_flag, &L.s_wait)) {
         bail(b);
         return;
       }
@@ -1644,12 +1975,14 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         const int *rec = a.ws.rec + 2 * o;
         for (int u = tid; u < Um; u += kBidThreads) {
           int tgt, rank, inc_bits, nxt;
-          if (u < kStash) {
+          const bool own = u < kStash && stash[u].next != kStashOpen;  // this workgroup emitted the slot's bid itself
+          if (own) {
             const BidStash sb = stash[u];
             tgt = sb.tgt;
             rank = sb.rank;
             inc_bits = sb.inc_bits;
             nxt = sb.next;
+            if (tgt == kStashDone) continue;  // re-flagged itself on arrival (emit_bid)
           } else {
             const int2 jr = ldc2(&llist[2 * u]);
             tgt = ldc(&bo.bid[o + jr.x]);
@@ -1671,7 +2004,8 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           int w_rank = -1, w_j = -1, p_inc = 0;
           float w_inc = 0.f;
           bool persist_hit = false;
-          for (int cr = rank, ci = inc_bits, cn = nxt;;) {
+          int steps = 0;
+          for (int cr = rank, ci = inc_bits, cn = nxt;; ++steps) {
             const float bi = __int_as_float(ci);
             if (last) {  // forced assignment (:200): every bidder takes its target; prices still accumulate (:209)
               stc(loc, &a.assignment[o + perm1[cr]], tgt);
@@ -1704,6 +2038,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
             ci = r2.x;
             cn = r2.y;
           }
+          if (steps >= 12) L.s_long = 1;  // one thread followed a dozen dependent loads: see emit_bid's outbid-skip
           stc(loc, &bo.head[o + tgt], -1);
           if (last) {
             stc(loc, &price[o + tgt], pr + w_inc);
@@ -1738,6 +2073,16 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
             __hip_atomic_fetch_add(nextbins + tid, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_bins[tid] = 0;
           }
+        }
+        if (tid == kRankBins && tsd) {  // contested targets: the next iteration's bidders check the maximum before they link
+          // switched ON by a long list, kept on while at least half of this workgroup's bidders find themselves
+          // outbid on arrival (with the skip on the lists are short, so the walkers no longer see the contention);
+          // uniform clouds: 20-30 % in the early iterations -- there the second round trip per bid costs 1.6 us per
+          // iteration and buys nothing
+          if (L.s_long || (L.s_skipped >= 16 && 2 * L.s_skipped >= Um))
+            stc(loc, reinterpret_cast<int *>(&tsd->cont[cur ^ 1]), (int)((stamp + 1u) & 0xffffffu));
+          L.s_long = 0;
+          L.s_skipped = 0;
         }
       }
       if (a.diag) __syncthreads();
@@ -1797,7 +2142,8 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
 
 constexpr size_t kDiagWords = 16 + 64 * 64;                        // int64 phase timers (SN_EMD_DIAG)
 constexpr size_t kCtlWords = 32 + 32 * 1024;                        // ticket, abort, up to 1024 team counters
-constexpr size_t kCtlBytes = 4 * kCtlWords + 8 * kDiagWords;
+constexpr size_t kStealBytes = 1024 * sizeof(TeamSteal);         // one TeamSteal per team
+constexpr size_t kCtlBytes = 4 * kCtlWords + kStealBytes + 8 * kDiagWords;
 
 EmdWs carve(void *workspace, int b, int n) {
   char *p = static_cast<char *>(workspace);
@@ -2129,7 +2475,15 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
-  emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
+  {
+    // SN_EMD_SEED=window: rounds 1-4's seeds (A/B, tools/emd_regimes.py); read per call
+    const char *e = getenv("SN_EMD_SEED");
+    const bool window = (n >> 4) > kSeedBlk || (e && e[0] == 'w');
+    if (window)
+      emd_seed_window_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
+    else
+      emd_seed_kernel<<<b * (n / kSeedThreads), kSeedThreads, 0, s>>>(b, n, xyz1, ws);
+  }
   {
     // one workgroup of 16 waves per CU (the register budget admits exactly one): the whole grid is resident
     // on an idle device, and the ticket order keeps it live next to other launches (see the kernel's header)
@@ -2159,13 +2513,20 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     args.diag = diag;
     static const unsigned spin_env = [] { const char *e = getenv("SN_EMD_SPIN_LIMIT"); return e ? (unsigned)atol(e) : 0u; }();
     args.spin_limit = (diag & 8) ? (1u << 15) : (spin_env ? spin_env : kSpinLimit);   // SN_EMD_SPIN_LIMIT: debugging aid
-    args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
+    args.steal = reinterpret_cast<TeamSteal *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
+    args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords + kStealBytes);
+    {  // read per call: the tests compare the settings inside one process
+      const char *e = getenv("SN_EMD_STEAL");
+      args.steal_mode = e ? atoi(e) : 1;
+      if (args.steal_mode < 0) args.steal = nullptr;  // no steal area at all: fixed strides, no outbid-skip feedback
+      e = getenv("SN_EMD_SKIP");
+      args.skip_mode = e ? atoi(e) : 1;
+    }
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
+    SN_HIP(hipMemsetAsync(args.steal, 0, sizeof(TeamSteal) * (size_t)args.tg.teams, s));
     {
-      // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
-      // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.
       // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
       // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.
       const hipError_t lds_rc = hipFuncSetAttribute(reinterpret_cast<const void *>(&emd_auction_kernel),

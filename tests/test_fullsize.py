@@ -194,8 +194,18 @@ def test_p2i_backward_bench_configuration(dev):
     for r, R in enumerate(radii):
         a, b_, c = oracle.p2i_max_backward(og[r].numpy(), ids_h[r], pts.numpy(), feat.numpy(), R)
         rp += a; rf += b_; rb += c
+    # (fp32-order bound of the ORACLE's sequential sums, see tests/test_p2i.py; the exact accumulation is pinned below)
     np.testing.assert_allclose(gp.cpu().numpy(), rp, rtol=3e-5, atol=3e-6)
     np.testing.assert_allclose(gf.cpu().numpy(), rf, rtol=3e-5, atol=3e-6)
+    ep = np.zeros((B * N, 2), np.float64)
+    ef = np.zeros((B * N, 1), np.float64)
+    for r, R in enumerate(radii):
+        a, b_ = oracle.p2i_max_backward_exact(og[r].numpy(), ids_h[r], pts.numpy(), feat.numpy(), R)
+        ep += a; ef += b_
+    # three radii: three exactly accumulated sums, each rounded once, added in double here and in ONE fixed-point
+    # accumulator on the device
+    np.testing.assert_allclose(gp.cpu().numpy(), ep, rtol=2e-6, atol=1e-7 * float(np.abs(ep).max()))
+    np.testing.assert_allclose(gf.cpu().numpy(), ef, rtol=2e-6, atol=1e-7 * float(np.abs(ef).max()))
     np.testing.assert_allclose(gb.cpu().numpy(), rb, rtol=1e-6, atol=1e-7)
 
 

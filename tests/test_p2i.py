@@ -98,6 +98,16 @@ def _close_maps(out, ids, ref_out, ref_ids, what, pts, feat, bg, R):
     assert ties <= max(2, ids.size // 10000), (what, ties)   # and they are rare
 
 
+def _assert_exact_accumulation(gp, gf, out_grad, ids, points, feat, R, what, scale=1.0):
+    """The fixed-point backward against the oracle's EXACT sum of the same fp32 terms: what is left is the one
+    rounding of the result, the 2^-45 fixed-point step and the last bit of a term (the HIP path evaluates
+    sin(pi r / R) / r with its own fp64 sequence): 2e-6 relative + 1e-7 of the largest gradient."""
+    ep, ef = oracle.p2i_max_backward_exact(out_grad, ids, points, feat, R)
+    ep = ep * scale
+    np.testing.assert_allclose(gp, ep, rtol=2e-6, atol=1e-7 * max(1.0, float(np.abs(ep).max())), err_msg=str(what))
+    np.testing.assert_allclose(gf, ef, rtol=2e-6, atol=1e-7 * max(1.0, float(np.abs(ef).max())), err_msg=str(what))
+
+
 @pytest.mark.gpu
 def test_hip_matches_functor_golden(golden_dir, dev):
     from sparenet_amd.cuda.p2i_op import ext
@@ -111,6 +121,14 @@ def test_hip_matches_functor_golden(golden_dir, dev):
         _close_maps(out.cpu().numpy(), ids.cpu().numpy(), z["max_out"], z["max_ids"], f,
                     z["points"], z["feat"], z["background"], R)
         gp, gf, gb = ext.p2i_max_backward_gpu(t["out_grad"], t["max_ids"], t["points"], t["feat"], 0, R)
+        # Tolerances of the gradient comparisons in this file.  A point's gradient is a SUM of up to ~pi R^2 signed
+        # fp32 terms (one per pixel it won).  The golden (the reference functor, run sequentially) and the oracle add
+        # them in fp32 in pixel order, the reference's GPU with fp32 atomics in arrival order: each of those sums is
+        # only defined up to (#terms) 2^-24 sum|terms| (80 ... 314 terms at R = 5 ... 10: 0.5 ... 2e-5 of the
+        # magnitude sum, more relative to a sum that cancels) -- the rtol 2e-5 ... 5e-5 / atol 2e-6 ... 5e-6 below are
+        # that bound, not slack of the HIP path.  The HIP path adds the same fp32 terms EXACTLY (64-bit fixed point)
+        # and is pinned much tighter against the oracle's exact accumulation of those terms
+        # (_assert_exact_accumulation: 2e-6 relative to the result, i.e. north_star's 1e-5 with room).
         np.testing.assert_allclose(gp.cpu().numpy(), z["max_points_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
         np.testing.assert_allclose(gf.cpu().numpy(), z["max_feat_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
         assert np.array_equal(gb.cpu().numpy(), z["max_background_grad"]), f
@@ -121,6 +139,8 @@ def test_hip_matches_functor_golden(golden_dir, dev):
         np.testing.assert_allclose(m1[1].cpu().numpy(), z["max_feat_grad"], rtol=2e-5, atol=2e-6, err_msg=f)
         assert np.array_equal(m1[2].cpu().numpy(), z["max_background_grad"]), f
         assert all(torch.equal(a, b) for a, b in zip(m1, m2)), "integer accumulation is order independent"
+        _assert_exact_accumulation(m1[0].cpu().numpy(), m1[1].cpu().numpy(), z["out_grad"], z["max_ids"], z["points"],
+                                   z["feat"], R, f)
         so = ext.p2i_sum_forward_gpu(t["points"], t["feat"], t["batch_inds"], t["background"], 0, R)
         np.testing.assert_allclose(so.cpu().numpy(), z["sum_out"], rtol=2e-5, atol=2e-6, err_msg=f)
         sgp, sgf = ext.p2i_sum_backward_gpu(t["out_grad"], t["points"], t["feat"], t["batch_inds"], 0, R)
@@ -245,6 +265,9 @@ def test_hip_p2i_autograd_vs_oracle(dev):
         np.testing.assert_allclose(p.grad.cpu().numpy(), gp * (S - 1) / 2, rtol=5e-5, atol=5e-6)
         np.testing.assert_allclose(f.grad.cpu().numpy(), gf, rtol=5e-5, atol=5e-6)
         np.testing.assert_allclose(b.grad.cpu().numpy(), gb, rtol=1e-6)
+        if reduce == "max":   # the fp32-order bound above is the oracle's; against the exact sum of the terms:
+            _assert_exact_accumulation(p.grad.cpu().numpy(), f.grad.cpu().numpy(), og.numpy(), ids, px, feat.numpy(), R,
+                                       "autograd", scale=(S - 1) / 2)
 
 
 @pytest.mark.gpu
@@ -272,7 +295,18 @@ def test_hip_fused_projection_matches_torch_glue(projection, dev):
         ((pix2 * wp).sum() + (feat2 * wf).sum()).backward()
         np.testing.assert_allclose(pix2.detach().cpu().numpy(), pix.detach().cpu().numpy(), rtol=1e-5, atol=2e-5)
         np.testing.assert_allclose(feat2.detach().cpu().numpy(), feat.detach().cpu().numpy(), rtol=1e-5, atol=3e-6)
+        # fp32 against fp32: the points that attain zmin / zmax collect a sum over ALL points, which torch's reduction
+        # and the fused kernel add in different orders -- two fp32 evaluations of one quantity only agree this far:
         np.testing.assert_allclose(d2.grad.cpu().numpy(), d1.grad.cpu().numpy(), rtol=2e-4, atol=2e-4)
+        # the contract (north_star: 1e-5) is against the VALUE: the same glue evaluated in float64
+        d3 = base.clone().double().to(dev).requires_grad_(True)
+        pos64, feat64 = cdm.project(d3, v)
+        ((((pos64 + 1) / 2 * 63.0) * wp.double()).sum() + (feat64 * wf.double()).sum()).backward()
+        ref = d3.grad.cpu().numpy()
+        scale = float(np.abs(ref).max())
+        err_hip = float(np.abs(d2.grad.cpu().numpy() - ref).max()) / scale
+        err_torch = float(np.abs(d1.grad.cpu().numpy() - ref).max()) / scale
+        assert err_hip <= 1e-5, (projection, v, "fused backward vs float64", err_hip, "torch fp32 mirror:", err_torch)
 
 
 @pytest.mark.gpu
