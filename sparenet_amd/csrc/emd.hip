@@ -263,6 +263,7 @@ struct EmdWs {
   int *flags;    // [B, n] by rank: unassigned after this iteration (next list = flagged ranks in order)
   int *hist1;    // [B, 4096] sort scratch of the bidders
   float *bbox1;  // [B, 6]
+  int *far;      // [B] bidders that lie far from their nearest seed (emd_seed_kernel; nullptr: not counted)
   void *ctl;     // persistent auction: ticket, abort word, one barrier counter per team
 };
 
@@ -303,6 +304,7 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
       ws.bins[0][e] = n / kRankBins;  // every bidder starts unassigned
       ws.bins[1][e] = 0;
     }
+    if (e < B) ws.far[e] = 0;
   }
 }
 
@@ -349,116 +351,17 @@ __global__ __launch_bounds__(256) void emd_sbbox_kernel(int B, int n, const floa
 
 // First-iteration seeds.  The bid filter needs, per bidder, two real targets whose values
 // bound the final `better` from below; later iterations use the previous favourites, the first
-// one has none.  ANY two distinct targets are valid seeds; better ones only make the filter reject more --
-// and how much more depends on the data: a window of the targets' Morton order around the bidder's own cell
-// (rounds 1-4, emd_seed_window_kernel below) finds near neighbours when the two clouds fill the same volume,
-// but for a prediction that lies OFF the targets' surface (early training: scattered around it, or the refine
-// stages of an untrained generator) the bidder's cell holds no target and its stream neighbours can be anywhere:
-// the first iteration of the scattered probe took 670 us of a 2.6 ms call at 4 clouds, the workgroups with the far
-// bidders 3x the average (profiles/r05_a_emd_regimes_before.txt).  emd_seed_kernel walks the box hierarchy the bid
-// phase uses anyway -- the 64 groups of 256 targets, then the 16-target blocks of the two nearest groups -- and takes
-// the two nearest targets of the two nearest blocks: ~130 box / point tests per bidder whatever the data.
-constexpr int kSeedThreads = 256;
-constexpr int kSeedBlk = 1024;  // blocks of 16 targets whose boxes fit the kernel's LDS (n <= 16384), as in bid_scan
-
-__device__ __forceinline__ float box_gap2(const f4 A, const f4 B, float x, float y, float z) {
-  const float gx = __builtin_fmaxf(__builtin_fmaxf(A.x - x, x - A.w), 0.f);
-  const float gy = __builtin_fmaxf(__builtin_fmaxf(A.y - y, y - B.x), 0.f);
-  const float gz = __builtin_fmaxf(__builtin_fmaxf(A.z - z, z - B.y), 0.f);
-  return (gx * gx + gy * gy) + gz * gz;
-}
-
-__global__ __launch_bounds__(kSeedThreads) void emd_seed_kernel(int B, int n, const float *__restrict__ xyz1,
-                                                                EmdWs ws) {
-#pragma clang fp contract(off)
-  __shared__ f4 s_blk[kSeedBlk][2];
-  __shared__ f4 s_hb[kSeedBlk / 16][2];
-  const int per = n / kSeedThreads;           // workgroups per cloud (n % 1024 == 0)
-  const int bb = blockIdx.x / per;
-  const int r = (blockIdx.x - bb * per) * kSeedThreads + threadIdx.x;  // the bidder's Hilbert rank: neighbours share blocks
-  const int nblk = n >> 4, nh = n >> 8;
-  {
-    const f4 *src = reinterpret_cast<const f4 *>(ws.sbbox + (size_t)bb * nblk * 8);
-    f4 *dst = &s_blk[0][0];
-    for (int i = threadIdx.x; i < 2 * nblk; i += kSeedThreads) dst[i] = src[i];
-  }
-  __syncthreads();
-  for (int h = threadIdx.x; h < nh; h += kSeedThreads) {
-    f4 lo = s_blk[16 * h][0], hi = s_blk[16 * h][1];
-    for (int q = 1; q < 16; ++q) {
-      const f4 l2 = s_blk[16 * h + q][0], h2 = s_blk[16 * h + q][1];
-      lo.x = __builtin_fminf(lo.x, l2.x);
-      lo.y = __builtin_fminf(lo.y, l2.y);
-      lo.z = __builtin_fminf(lo.z, l2.z);
-      lo.w = __builtin_fmaxf(lo.w, l2.w);
-      hi.x = __builtin_fmaxf(hi.x, h2.x);
-      hi.y = __builtin_fmaxf(hi.y, h2.y);
-    }
-    s_hb[h][0] = lo;
-    s_hb[h][1] = hi;
-  }
-  __syncthreads();
-  const size_t o = (size_t)bb * n;
-  const int j = ws.perm1[o + r];
-  const float x = xyz1[(o + j) * 3 + 0], y = xyz1[(o + j) * 3 + 1], z = xyz1[(o + j) * 3 + 2];
-  // the two nearest groups of 256 targets (by box distance), then the two nearest blocks among their 32
-  float g1 = 3e38f, g2 = 3e38f;
-  int h1 = 0, h2 = 0;
-  for (int h = 0; h < nh; ++h) {
-    const float g = box_gap2(s_hb[h][0], s_hb[h][1], x, y, z);
-    if (g < g1) {
-      g2 = g1;
-      h2 = h1;
-      g1 = g;
-      h1 = h;
-    } else if (g < g2) {
-      g2 = g;
-      h2 = h;
-    }
-  }
-  if (nh < 2) h2 = h1;
-  float c1 = 3e38f, c2 = 3e38f;
-  int b1 = 16 * h1, b2 = 16 * h1 + 1;
-  for (int t = 0; t < (h2 == h1 ? 16 : 32); ++t) {
-    const int blk = (t < 16 ? 16 * h1 : 16 * h2 - 16) + t;
-    const float g = box_gap2(s_blk[blk][0], s_blk[blk][1], x, y, z);
-    if (g < c1) {
-      c2 = c1;
-      b2 = b1;
-      c1 = g;
-      b1 = blk;
-    } else if (g < c2) {
-      c2 = g;
-      b2 = blk;
-    }
-  }
-  float s1 = 3e38f, s2 = 3e38f;
-  int k1 = -1, k2 = -1;
-  for (int t = 0; t < 32; ++t) {  // the prepared stream: one 16-byte record per position
-    const f4 tg = ws.t4s[o + 16 * (t < 16 ? b1 : b2) + (t & 15)];
-    const int k = __float_as_int(tg.w);
-    const float dx = tg.x - x, dy = tg.y - y, dz = tg.z - z;
-    const float sq = (dx * dx + dy * dy) + dz * dz;
-    if (sq < s1) {
-      s2 = s1;
-      k2 = k1;
-      s1 = sq;
-      k1 = k;
-    } else if (sq < s2) {
-      s2 = sq;
-      k2 = k;
-    }
-  }
-  ws.bid[o + j] = k1;
-  ws.bid2[o + j] = k2;
-  // the reference's max_idx tensor starts as zeros = "bidder 0" (emd_module.py:50); kept here as a RANK
-  ws.max_idx[o + r] = ws.rank1[o];
-}
-
-// The window form (clouds whose block boxes do not fit the LDS copy, n > 16384): targets are already in Morton
-// order; a window of 16 sorted positions around the bidder's own cell supplies candidates, the two nearest
-// become bid / bid2.
-__global__ __launch_bounds__(kThreads) void emd_seed_window_kernel(int B, int n,
+// one has none and would evaluate ~75 targets per bidder exactly before its thresholds
+// tighten.  ANY two distinct targets are valid seeds; better ones only make the filter reject more.
+// Targets are already in Morton order: a window of 16 sorted positions around the
+// bidder's own cell supplies candidates, the two nearest become bid / bid2.
+// The kernel also COUNTS (on a sample of the waves) the bidders that lie far from the targets: a prediction off
+// the targets' surface is data on which the auction bids with the scan from the first iteration on (see the
+// kernel's bid phase).  (Round 5 also built seeds from the box hierarchy -- the two nearest groups of 256 targets,
+// their nearest blocks, the two nearest targets of those: better seeds for far bidders, 13 us less in the first
+// iteration of the scattered probe; once such clouds bid with the scan it made no difference any more -- 3.98 vs
+// 3.99 ms per call -- and the kernel cost 40 us of LDS fills on every cloud: removed.)
+__global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
                                                             const float *__restrict__ xyz1,
                                                             const float *__restrict__ xyz2,
                                                             EmdWs ws) {
@@ -504,6 +407,17 @@ __global__ __launch_bounds__(kThreads) void emd_seed_window_kernel(int B, int n,
     ws.bid2[je] = k2;
     // the reference's max_idx tensor starts as zeros = "bidder 0" (emd_module.py:50); kept here as a RANK
     ws.max_idx[e] = ws.rank1[bb * n];
+    // Is this bidder FAR from the targets -- farther from its nearest seed than a quarter of the width of the block of
+    // 16 stream neighbours it looked at?  (uniform cubes: 8 % of the bidders, prediction = ground truth + 1 % noise:
+    // none, scattered +-0.3 around the surface: 58 %, the refine stages of an untrained generator: 85 %.)  Counted on
+    // every eighth wave, scaled by 8: one atomic per wave on the cloud's counter took 58 us at 32 clouds (256
+    // serialised atomics per word), an eighth of them is an estimate that is good enough for a 25 % threshold.
+    if (((e >> 6) & 7) == 0) {  // wave-uniform (n % 1024 == 0: a wave never straddles two clouds)
+      const float *bx = ws.sbbox + (bb * (n >> 4) + ((lo + 8) >> 4)) * 8;
+      const float ex = bx[3] - bx[0], ey = bx[4] - bx[1], ez = bx[5] - bx[2];
+      const unsigned long long farm = __ballot(16.f * s1 > (ex * ex + ey * ey) + ez * ez);
+      if ((threadIdx.x & 63) == 0 && farm != 0ull) atomicAdd(&ws.far[bb], 8 * __popcll(farm));
+    }
   }
 }
 
@@ -513,12 +427,7 @@ struct BidOut {
   float *max_inc;
   int *head;
   bool loc;  // the team sits on one XCD: plain stores (see stc)
-  // outbid-skip (see emit_bid): 0 = off, else the bidder re-flags itself through these
-  int skip;
-  int *flags;    // [n] of this cloud, by rank
-  int *s_bins;   // LDS counters of re-flagged bidders per rank bin
-  int binsize;
-  int *s_skipped;  // LDS: bidders this workgroup re-flagged on arrival in this iteration
+  int skip;  // outbid-skip (see emit_bid): 0 = off
 };
 
 #ifndef SN_EMD_BIDWAVES
@@ -535,13 +444,12 @@ constexpr int kStash = kBidThreads;  // list slots whose bid is handed to the aw
 
 // What the award phase needs to know about the bid of list slot u (written by the wave that emits the bid, read
 // after the team barrier by thread u): saves the llist -> bid -> rec chain of dependent coherent loads.
-// next == kStashOpen: the slot's bid was NOT emitted by this workgroup (another workgroup of the team took the
-// bidder over, see "work hand-off" in the kernel): the award phase reads the record from global memory.
-// tgt == kStashDone: the bidder re-flagged itself in the bid phase (outbid on arrival): nothing left to do.
+// next == kOutbid (also in rec[rank].next): the bidder found itself outbid on arrival and did not link itself
+// (emit_bid): the award phase only re-flags it.
 struct BidStash {
   int tgt, rank, inc_bits, next;
 };
-constexpr int kStashOpen = -2, kStashDone = -2;
+constexpr int kOutbid = -3;
 
 // The bid of bidder j (Morton rank `rank`, list slot u).  Besides the favourites (next iteration's filter seeds)
 // and the running maximum of the target's increments (emd_cuda.cu:175-177), the bidder LINKS itself into the
@@ -553,18 +461,19 @@ constexpr int kStashOpen = -2, kStashDone = -2;
 // that finds the word already above inc + 1e-6 (the reference's double compare) can never be inside the window,
 // whatever arrives later.  For eps >= 0 somebody always IS inside it (the bidder that sets the maximum; the word
 // starts at 0 <= every increment), so the persistent max_idx entry never decides and such a bidder simply stays
-// unassigned (emd_cuda.cu:200: neither forced nor the winner): it re-flags itself here and does not enter the
-// list.  With L bidders on one target arriving in random order ~ln L of them link themselves: on the refine stages
+// unassigned (emd_cuda.cu:200: neither forced nor the winner): it does not enter the list; its record says so and
+// the award phase re-flags it (there, not here: the flag array, the bin counters and the bin size would otherwise
+// be live through the whole bid phase of a kernel that sits at its register limit -- 13 more spilled VGPRs).  With L bidders on one target arriving in random order ~ln L of them link themselves: on the refine stages
 // of an untrained generator (hundreds of far bidders on every near target: lists of 200-480, walked by ONE thread
 // at a dependent load per entry) 7000 bidders leave 1400 list entries, the longest list 10
 // (tools/sim/auction_regime_stats.c).  Costs one more dependent round trip per bid (the maximum must RETURN the old
 // value before the exchange), so it is switched on per iteration by the lists the award phase walked in the
 // previous one (the team's `cont` word).  Never in the last iteration (every bidder takes its target there) and
 // never for eps < 0.
-__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int rank, int u, bool local,
-                                         BidStash *stash, const Top2 &top, float eps) {
+__device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int rank, int u, BidStash *stash,
+                                         const Top2 &top, float eps) {
   const bool loc = A.loc;
-  const bool st = local && u < kStash;
+  const bool st = u < kStash;
   if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
     stc(loc, &A.bid[o + j], -1);
     stc(loc, &A.bid2[o + j], -1);
@@ -575,13 +484,15 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int r
   const float inc = (top.best - top.better) + eps;
   stc(loc, &A.bid[o + j], top.best_i);
   stc(loc, &A.bid2[o + j], top.better_i == top.best_i ? -1 : top.better_i);
+#ifdef SN_EMD_NOSKIP
+  if (false) {
+#else
   if (A.skip) {
+#endif
     const float before = atomic_max_float_old(&A.max_inc[o + top.best_i], inc);
     if ((double)before > (double)inc + 1e-6) {  // outbid already: stays unassigned, bids again
-      stc(loc, &A.flags[rank], 1);
-      atomicAdd(&A.s_bins[rank / A.binsize], 1);
-      atomicAdd(A.s_skipped, 1);
-      if (st) stash[u] = BidStash{kStashDone, rank, 0, -1};
+      stc2(loc, &A.rec[2 * (o + rank)], __float_as_int(inc), kOutbid);
+      if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), kOutbid};
       return;
     }
   } else {
@@ -709,33 +620,20 @@ struct AuctionCtl {  // zeroed by a memset node before every launch
   unsigned bar[1];  // [teams * 32]: one counter per team, 128 bytes apart
 };
 
-// Work hand-off inside a team (one block per team, zeroed by a memset node before every launch).
-// The ranks are split by bidder COUNT; what a bidder costs depends on the data -- on clouds scattered around a
-// surface a bidder's reach holds 25 blocks on average and up to 330 (tools/sim/auction_regime_stats.c) -- and on
-// such data the team waited at the first barrier of every iteration for the workgroup that happened to own the
-// expensive bidders: 1.25 of a 2.6 ms call at 4 clouds, 16.5 of 79 ms on the refine stages of an untrained
-// generator at 32 (profiles/r05_a_emd_regimes_before.txt).  A workgroup whose list holds more than one chunk per
-// wave (scan: 4 bidders; matrix-core search: a group of 64) PUBLISHES it -- {stamp, count, first rank} in one 64-bit
-// word, after its list has reached the L2 -- and its waves take chunks beyond the first kBidWaves from a cursor
-// instead of a fixed stride; a wave of ANOTHER workgroup of the team that has run out of work reads the team's
-// words, picks the workgroup with most chunks left, and takes chunks from the same cursor (bid_scan / bid_group with
-// local == false: the list entry is read from global memory, the bid reaches the award phase through global memory;
-// the owner's award phase finds the slot's stash still open).  Which wave serves a bidder never enters a result.
-// Nobody waits for anybody: an unpublished word (stale stamp) is skipped.  Not in the fenced fallback mode.
-struct TeamSteal {
-  unsigned long long pub[2][32];  // [iteration parity][member]: stamp : 24 | bidders : 20 | first rank : 20
-  unsigned cur[2][32];            // [iteration parity][member]: chunks taken beyond the static first kBidWaves
-  unsigned cont[2];               // [iteration parity]: stamp of the iteration that should skip outbid bidders (emit_bid)
-  unsigned pad[62];
-};
-static_assert(sizeof(TeamSteal) == 1024, "TeamSteal");
-// Looking costs every wave two coherent loads and a reduction (~2.5 us): only a workgroup that polled the previous
-// first barrier at least this often (~10 us; balanced teams wait 3-5) looks for work, and only while the team has
-// enough bidders for anybody to have published a list.  Always-look cost 0.33 ms of a 2.0 ms call on uniform clouds.
-#ifndef SN_EMD_STEAL_POLLS
-#define SN_EMD_STEAL_POLLS 14
-#endif
-constexpr int kStealWaitPolls = SN_EMD_STEAL_POLLS;
+// Two words per team (zeroed by the memset node before every launch): what one iteration tells the next.
+//   cont[parity] = stamp of the iteration that should treat the auction as CONTESTED (hundreds of bidders per
+//   target): its bidders check the target's running maximum before they link themselves (emit_bid's outbid-skip) and
+//   every workgroup bids with the scan.  Stamps grow from cloud to cloud and from iteration to iteration, so a word
+//   left by an earlier cloud or iteration never looks like this iteration's.
+// (Round 5 also built a work HAND-OFF on top of such a block -- a workgroup published its list, waves of workgroups
+// that had finished took chunks of it through a per-workgroup cursor: bit-exact, and slower on every kind of data:
+// hundreds of idle waves converge on the cursor of the one slow workgroup, whose own waves then queue behind them for
+// every chunk; the iteration of the scattered probe got 70 % longer while the thieves were busy
+// (profiles/r05_a_emd_handoff_not_kept.txt).  What balances the team instead is WHICH ranks a workgroup owns: see
+// the split at the top of an iteration.)
+// The words live in the team's 128-byte barrier block (AuctionCtl::bar + 32 team: word 0 the counter, word 1 the
+// mixed-XCD flag, words 2-3 cont[2]): zeroed with it, no second memset node.
+constexpr int kNoteWord = 2;
 
 struct TeamGeom {
   int G;       // workgroups per team (power of two)
@@ -797,10 +695,7 @@ struct TeamSync {
 // L1, sc1 accesses meeting in the L2 / at the fabric), which the HIP memory model does not promise: the library
 // verifies it once per device with a litmus kernel (emd_litmus_kernel) and falls back to `fenced` barriers +
 // agent-scope stores when the check fails or SN_EMD_SAFE=1 is set.
-// s_wait (optional, LDS): how long this workgroup waited for the others, in polls of the counter (~0.7 us each: a
-// sleep + one coherent load) -- the work hand-off's signal that the team is out of balance.  (Not the realtime
-// clock: two s_memrealtime reads cost 0.5 us of every barrier.)
-__device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag, int *s_wait = nullptr) {
+__device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __syncthreads();
@@ -822,7 +717,6 @@ __device__ __forceinline__ bool team_barrier(TeamSync &ts, int *s_flag, int *s_w
       }
     }
     *s_flag = ok;
-    if (s_wait) *s_wait = (int)spins;
   }
   __syncthreads();
   if (ts.fenced) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -845,17 +739,15 @@ struct BidCtx {
   const float *sbb;  // block boxes of this cloud
   BidOut A;
   BidStash *stash;   // LDS, kStash entries
+  bool offsurf;      // far or contested data: bid_scan tightens its reach between lists
 #ifdef SN_BID_STAMPS
   long long *stamps;  // experiment build: per-wave time per part of bid_group (100 MHz ticks), or nullptr
 #endif
 };
 
 // One group of 64 bidders, seen by one of its S segment-waves.
-// S == 1: the wave serves the group alone (its GroupAcc slot is private, no workgroup barrier inside): the form in
-// which a wave takes groups over -- from its own workgroup's cursor or from another workgroup of the team
-// (local == false: `lst` / `count` are that workgroup's list, the bid goes to the award phase through global memory).
 __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc &ga, const int *lst,
-                                          int count, int grp, int ngroups, int S, int seg, int lane, bool local) {
+                                          int count, int grp, int ngroups, int S, int seg, int lane) {
   const int row = lane >> 4, col = lane & 15;
   const int u = grp * 64 + lane;
   const bool active = grp < ngroups && u < count;
@@ -894,7 +786,9 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
     ga.sj[lane] = jj;
     ga.sr[lane] = jr.y;
   }
-  if (S > 1) __syncthreads();  // every wave of the workgroup calls bid_group the same number of times
+  // every wave of the workgroup calls bid_group the same number of times.  (With S == 1 the hand-over is private to the
+  // wave and the barrier is not needed for correctness; without it the waves drift apart and the call is 1.3 % slower.)
+  __syncthreads();
   if (grp < ngroups) {  // wave-uniform
     j = ga.sj[lane];
     float blo[4][3], bhi[4][3];
@@ -1185,7 +1079,7 @@ __device__ __forceinline__ void bid_group(const BidCtx &c, WaveTab &T, GroupAcc 
       atomicExch(&ga.lock, 0);
     }
   }
-  if (emit && active) emit_bid(c.A, c.o, j, ga.sr[lane], u, local, c.stash, top, c.eps);
+  if (emit && active) emit_bid(c.A, c.o, j, ga.sr[lane], u, c.stash, top, c.eps);
 #ifdef SN_BID_STAMPS
   STAMP(4)
   if (c.stamps && lane == 0)
@@ -1255,23 +1149,8 @@ struct ScanCand {  // one round of a quarter wave: lane c holds target c of each
 };
 
 
-// A workgroup's `count` bidders are served in PASSES of kQuarters quarter waves; T = 1 / 2 / 4 quarters share a
-// bidder in a pass that has at most kQuarters / T bidders left (only the last pass can).  A CHUNK is one wave's
-// share of a pass -- 4 / T bidders -- and the unit in which waves take work: chunk c = pass c / kBidWaves, wave
-// slot c % kBidWaves.  scan_chunks(count) = the number of chunks that hold a bidder.
-constexpr int kQuarters = kBidWaves * 4;  // quarter waves of a workgroup
-__device__ __forceinline__ int scan_tsh(int rem) { return rem <= kQuarters / 4 ? 2 : (rem <= kQuarters / 2 ? 1 : 0); }
-__device__ __forceinline__ int scan_chunks(int count) {
-  if (count <= 0) return 0;
-  const int full = (count - 1) / kQuarters;        // passes before the last one: kQuarters bidders each
-  const int rem = count - full * kQuarters;        // 1 .. kQuarters
-  return full * kBidWaves + (((rem << scan_tsh(rem)) + 3) >> 2);
-}
-
-// `wave`: the EXECUTING wave (its LDS list); `chunk`: which bidders; local: the list is this workgroup's own (the
-// entries wait in the stash, the bid is handed to the award phase through it).
-__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int chunk,
-                                         bool local, int wave, int lane) {
+__device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int *lst, int count, int wave,
+                                         int lane) {
   const int row = lane >> 4, col = lane & 15;
   const int nh = c.nsb >> 2;  // groups of 16 blocks
   const int nblk = c.nsb << 2;
@@ -1290,10 +1169,12 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
 #define STAMP(i)
 #define COUNT(i, v)
 #endif
-  {
-    const int u0 = (chunk / kBidWaves) * kQuarters;
-    const int tsh = scan_tsh(count - u0), T = 1 << tsh;  // uniform in the pass
-    const int qd = (chunk % kBidWaves) * 4 + row;
+  for (int u0 = 0; u0 < count;) {
+    // T quarter waves per bidder: with few bidders left a bidder's superblocks are dealt out to 2 or 4 quarters
+    const int rem = count - u0;
+    constexpr int kQuarters = kBidWaves * 4;  // quarter waves of the workgroup (qd below runs over them)
+    const int tsh = rem <= kQuarters / 4 ? 2 : (rem <= kQuarters / 2 ? 1 : 0), T = 1 << tsh;  // uniform in the workgroup
+    const int qd = wave * 4 + row;
     const int u = u0 + (qd >> tsh), part = qd & (T - 1);
     const bool active = u < count;  // uniform within the quarter
     int jj = 0, rank = 0, ba = -1, bb = -1;  // ba, bb: the blocks of the two previous favourites
@@ -1302,7 +1183,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       // two round trips: {coordinates, previous favourites} of the bidder, then the favourites' coordinates and
       // prices BY INDEX (the caller's array and the price array of the award phase; their stream positions, needed
       // for the lists only, arrive beside them)
-      if (local && u < kStash) {  // left there by the compaction
+      if (u < kStash) {  // left there by the compaction
         jj = c.stash[u].tgt;
         rank = c.stash[u].rank;
       } else {
@@ -1474,6 +1355,28 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       }
       first = false;
       asm volatile("" ::: "memory");
+#ifndef SN_SCAN_NO_RETIGHTEN
+      // (Only on such data -- c.offsurf: on uniform clouds and on a prediction that lies on the targets' surface the
+      // first reach is nearly the final one and the extra exchange cost 2 % of the call.)
+      // A second SWEEP for the heaviest bidders (a wave instead of a quarter each, through a table in LDS) was
+      // measured on top: 3.87 -> 3.70 ms on the scattered probe at 32 clouds with the threshold at 8 groups, the early
+      // iterations -- where many bidders are "heavy" and serialise in the table -- slower, uniform clouds +4 %
+      // (the barrier that completes the table); not kept.
+      // More groups to go: the blocks listed next are tested against the reach of what the team has SEEN by now, not
+      // of what it knew at the start (the two previous favourites at today's prices, or iteration 0's seeds).  The
+      // precise filter's bound max(cm, lane's better, qlb) is never below max(cm, qlb), so a block outside this reach
+      // holds nothing that passes it.  What it buys depends on the data: on a prediction scattered around the
+      // targets 1 % of the bidders start with 200-380 blocks within reach (tools/sim, iteration 0) and were the
+      // reason a workgroup took three times as long as the average one; after the first list (<= 48 blocks, the
+      // favourites' first) the bound is close to final and most of the rest fails the box test.
+      if (c.offsurf && __any(hm != 0ull)) {
+#pragma clang fp contract(off)
+        share();
+        const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
+        const float v = coarse_threshold(__builtin_fmaxf(cm, qlb), 2.f * 3.814697265625e-06f * (c.tmax + xx), c.a_max);
+        r2 = active ? (v > 0.f ? v * 1.0001f : v) : r2;
+      }
+#endif
       STAMP(2)
     } while (__any(hm != 0ull));
     // the quarter's 16 partial results: xor 1, xor 2, mirror within 8, mirror within 16; then the team's quarters
@@ -1493,8 +1396,9 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       const int oi = __shfl_xor(top.best_i, d), oi2 = __shfl_xor(top.better_i, d);
       top2_merge(top, ob, obb, oi, oi2, geom);
     }
-    if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, local, c.stash, top, c.eps);
+    if (active && col == 0 && part == 0) emit_bid(c.A, c.o, jj, rank, u, c.stash, top, c.eps);
     STAMP(4)
+    u0 += kQuarters >> tsh;
   }
 #ifdef SN_BID_STAMPS
   if (c.stamps && lane == 0)
@@ -1523,11 +1427,11 @@ struct AuctionArgs {
              // (sn_emd_diag_offset), zeroed by the call.  Bit 2 (4): every team a mixed-XCD one; bit 3 (8): the
              // second workgroup of team 0 leaves at once and barriers give up early (tests the time-out path).
   long long *dwords;
+  int diag_m0;   // SN_EMD_DIAG_M0: the first of the eight workgroups of team 0 whose per-iteration times are recorded
   int scan_max;  // iterations with at most this many bidders in the workgroup take bid_scan (0: never)
   int prof;      // 1: record the execution window in the control block (sn_prof_enable)
-  TeamSteal *steal;  // one block per team
-  int steal_mode;    // work hand-off: 0 never, 1 when the previous first barrier made this workgroup wait (default), 2 always look
-  int skip_mode;     // outbid-skip: 0 never, 1 after an iteration with long lists (default), 2 always
+  int skip_mode;     // contested-auction handling (outbid-skip + scan everywhere): 0 never, 1 when the lists say so (default), 2 always
+  int spread_mode;   // interleaved rank split in scan iterations: 0 never, 1 default, 2 in every iteration
 };
 
 // The kernel's LDS, carved from the DYNAMIC segment on purpose: with a static 101 KB the compiler derives "one
@@ -1542,7 +1446,7 @@ struct AuctionLds {
   BidStash stash[kStash];
   int wsum[kBidWaves];
   int s_flag, s_ticket, s_stray, s_range[4], s_bins[kRankBins];
-  int s_wait, s_long, s_skipped;
+  int s_long, s_skipped;
   ScanLds scan;
 };
 
@@ -1560,7 +1464,6 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   int &s_flag = L.s_flag, &s_ticket = L.s_ticket, &s_stray = L.s_stray;
   int *s_range = L.s_range, *s_bins = L.s_bins;
   if (threadIdx.x == 0) {
-    L.s_wait = 1 << 30;  // no history yet: the first iteration looks for work
     L.s_long = 0;
     L.s_skipped = 0;
   }
@@ -1650,17 +1553,19 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   const int lane = tid & 63;
   const int Rs = n / G, rs0 = m * Rs;  // static slice (final distances); n % 1024 == 0, G <= 64
   const int binsize = n / kRankBins;   // ranks per counter bin (a multiple of 4: n % 1024 == 0)
+  // the transposed bin order of scan iterations (see the split): G = 2^gsh workgroups, K = 256 / G bins each,
+  // position p = bin ((p mod K) << gsh) + (p >> ksh); only when a bin is a power-of-two number of 4-rank words
+  // (the shifts are derived where they are used: four more values live across the bid phase cost five spills)
+  auto transposed_bin = [&](int p) {
+    const int gsh = 31 - __builtin_clz((unsigned)G);
+    return ((p & ((kRankBins >> gsh) - 1)) << gsh) + (p >> (8 - gsh));
+  };
   const int block_cnt = n / 1024;
   float *price = a.ws.price;
   int *flags = a.ws.flags;
   int *llist_all = a.ws.list[0];
-  BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc, 0, nullptr, s_bins, binsize, &L.s_skipped};
-  // work hand-off / outbid-skip state of this team (TeamSteal); XCD-geometry teams only (they have a formation barrier)
-#ifdef SN_EMD_NOSTEAL   // experiment builds: the hand-off compiled out
-  TeamSteal *const tsd = nullptr;
-#else
-  TeamSteal *const tsd = (a.steal && a.tg.xcd && G > 1 && G <= 32 && !a.safe) ? a.steal + team : nullptr;
-#endif
+  BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc, 0};
+  unsigned *const note = a.ctl->bar + (size_t)team * 32 + kNoteWord;  // cont[2] of this team (see kNoteWord)
   int cloud_seq = 0;
   if (a.diag && m == 0 && tid == 0 && loc) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + 12, 1ull);  // teams on one XCD
 
@@ -1687,7 +1592,6 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
     c.rk2 = a.ws.rank2 + o;
     c.ms = a.ws.mstream + (size_t)b * nsb * 64;
     c.sbb = a.ws.sbbox + (size_t)b * nsb * 32;
-    bo.flags = flags + o;
     c.A = bo;
     c.stash = stash;
     const int *perm1 = a.ws.perm1 + o;
@@ -1695,11 +1599,9 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
     // never looks like this iteration's
     const unsigned stamp0 = (unsigned)cloud_seq * (unsigned)(a.iters + 1);
     ++cloud_seq;
-    if (tsd && tid == 0) {  // a cloud that ended early (U == 0) may have left its last cursor used
-      stc(loc, reinterpret_cast<int *>(&tsd->cur[0][m]), 0);
-      stc(loc, reinterpret_cast<int *>(&tsd->cur[1][m]), 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // ... before this workgroup can publish anything
-    }
+    // the prediction lies OFF the targets (more than a quarter of the bidders farther from their nearest seed than a
+    // quarter of that seed's block is wide; counted by emd_seed_kernel): see the bid phase
+    const bool far = a.ws.far != nullptr && 4 * a.ws.far[b] > n;
     // bid_scan's copy of the cloud's box hierarchy (constant for the whole call)
     const bool scan_ok = a.scan_max > 0 && 4 * nsb <= kScanBlk;  // nsb % 16 == 0 (n % 1024 == 0)
     if (scan_ok) {
@@ -1740,17 +1642,66 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
       // of the team derives the same split of the ranks into G contiguous, equally loaded ranges (bins are
       // indivisible).  A static split left the team waiting ~20 us per late iteration for the workgroup
       // whose region happened to hold two groups of bidders instead of one.
-      if (wave == 0) {  // lane l holds the bins 4 l .. 4 l + 3
+      //
+      // WHICH bins a workgroup owns (round 5).  A contiguous range of the Hilbert ranks keeps a workgroup's bidders
+      // spatial neighbours -- what the matrix-core search needs (a group of 64 list neighbours shares its reach) --
+      // but what a bidder COSTS is a property of where it lies: on a prediction scattered around the targets' surface
+      // a bidder's reach holds 25 blocks on average and up to 330 (tools/sim/auction_regime_stats.c), the expensive
+      // ones are neighbours, and the team waited at the first barrier of every iteration for the workgroup that owned
+      // them (1.25 of a 2.6 ms call at 4 clouds, 16.5 of 79 ms on the refine stages of an untrained generator at 32:
+      // profiles/r05_a_emd_regimes_before.txt).  In the iterations that bid with the SCAN (one bidder per quarter
+      // wave: nothing shared between list neighbours) the same count-balanced split therefore runs over the bins in
+      // TRANSPOSED order, position p = bin (p mod K) G + p div K, K = 256 / G: a workgroup's run of positions is a
+      // comb of bins spread evenly over the whole curve, every workgroup a sample of every region.  No protocol, no
+      // atomics; the bidders' order inside a list never enters a result.
+      const unsigned stamp = (stamp0 + (unsigned)it + 1u) & 0xffffffu;
+      const bool last = it == a.iters - 1;
+      if (wave == 0) {  // lane l holds the bins (positions) 4 l .. 4 l + 3
         const int2 lo2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane);
         const int2 hi2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane + 2);
-        const int v[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
-        const int lsum = (v[0] + v[1]) + (v[2] + v[3]);
+        int contw = 0;
+        if (lane == 0) contw = ldc(reinterpret_cast<const int *>(&note[cur]));
+        contw = __builtin_amdgcn_readfirstlane(contw);
+        int v[4] = {lo2.x, lo2.y, hi2.x, hi2.y};
+        int lsum = (v[0] + v[1]) + (v[2] + v[3]);
         int incl = lsum;
         for (int d = 1; d < 64; d <<= 1) {
           const int t = __shfl_up(incl, d);
           if (lane >= d) incl += t;
         }
         const int total = __shfl(incl, 63);
+        // contested auction (emit_bid's outbid-skip, the scan for every workgroup): for eps >= 0, not in the last
+        // iteration, when the previous iteration's award phase said so
+        const bool contested = a.eps >= 0.f && !last && (a.skip_mode == 2 || (a.skip_mode == 1 && (unsigned)contw == stamp));
+        const int smax = ((contested || far) && a.scan_max > 0 && a.scan_max < kScanContested) ? kScanContested : a.scan_max;
+        // (only where the cost per bidder is what varies: off-surface / contested data.  On uniform clouds and on a
+        // prediction on the targets' surface the transposed order costs 1.5-4 % -- a workgroup's bidders no longer
+        // share target blocks in its L1 -- and balances nothing: SN_EMD_SPREAD=3 spreads every scan iteration.)
+        const bool spread_ok = G > 1 && G <= kRankBins / 4 && ((binsize >> 2) & ((binsize >> 2) - 1)) == 0;
+        const bool spread = spread_ok && scan_ok &&
+                            (a.spread_mode == 2 || ((a.spread_mode == 3 || (a.spread_mode == 1 && (contested || far))) &&
+                                                    4 * total <= 3 * G * smax));
+#ifdef SN_EMD_NOSPREAD
+        if (false) {
+#else
+        if (spread) {  // the same counters in transposed order (through LDS: a wave's own writes, in order)
+#endif
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_bins[4 * lane + q] = v[q];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int p = 4 * lane + q;
+            v[q] = s_bins[transposed_bin(p)];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_bins[4 * lane + q] = 0;  // the award phase counts in these
+          lsum = (v[0] + v[1]) + (v[2] + v[3]);
+          incl = lsum;
+          for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+          }
+        }
         // a bin goes to the workgroup its MIDPOINT falls to in the ideal split (boundaries land on the bin edge
         // nearest to m total / G): with 256 bins a workgroup's load is within a couple of bidders of total / G,
         // so that it needs a second group of 64 only when the ideal split does
@@ -1763,22 +1714,19 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           cnt += __popcll(__ballot(own == m));
           excl += v[q];
         }
-        int contw = 0;
-        if (tsd && lane == 0) contw = ldc(reinterpret_cast<const int *>(&tsd->cont[cur]));
         if (lane == 0) {
           s_range[0] = total;
-          s_range[1] = first * binsize;
-          s_range[2] = cnt * binsize;
-          s_range[3] = contw;
+          s_range[1] = first;
+          s_range[2] = cnt;
+          s_range[3] = (contested ? 1 : 0) | (spread ? 2 : 0);
         }
       }
       __syncthreads();
-      const int U = s_range[0], r0 = s_range[1], R = s_range[2];
+      const int U = s_range[0], p0 = s_range[1], R = s_range[2] * binsize;
       if (U == 0) break;  // every workgroup of the team reads the same value
-      const unsigned stamp = (stamp0 + (unsigned)it + 1u) & 0xffffffu;
-      if (tsd && tid == 64) stc(loc, reinterpret_cast<int *>(&tsd->cur[cur ^ 1][m]), 0);  // the next iteration's cursor (last used two barriers ago)
+      const bool contested = (s_range[3] & 1) != 0, spread = (s_range[3] & 2) != 0;
+      const int r0 = p0 * binsize;  // where the workgroup's list lives (by position: disjoint whatever the order)
       int *llist = llist_all + 2 * (o + r0);   // {index, rank} pairs
-      const bool last = it == a.iters - 1;
       if (m == 0 && tid == 0 && a.stats) {
         atomicAdd(reinterpret_cast<unsigned long long *>(a.stats), (unsigned long long)U * n);
         if (b == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.stats) + 1, 1ULL);
@@ -1792,7 +1740,8 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         if (dg) {
           const long long now = (long long)__builtin_amdgcn_s_memrealtime();
           if (m == 0) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + slot, (unsigned long long)(now - tk));
-          if (a.diag >= 2 && m < 8 && it < 64) a.dwords[16 + ((it * 8 + m) * 8 + (slot - 4))] = now - tk;
+          if (a.diag >= 2 && m >= a.diag_m0 && m < a.diag_m0 + 8 && it < 64)
+            a.dwords[16 + ((it * 8 + (m - a.diag_m0)) * 8 + (slot - 4))] = now - tk;
           tk = now;
         }
       };
@@ -1804,11 +1753,21 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         for (int w0 = 0; w0 < vec; w0 += kBidThreads) {
           const int w = w0 + tid;
           int4 f = make_int4(0, 0, 0, 0);
+          // word w of the workgroup's positions: position p0 + w / wpb, i.e. bin p (contiguous) or its transpose
+          int rw = r0 + 4 * w;
           if (w < vec) {  // coherent reads (other workgroups raised these flags), two 8-byte words per lane
-            const int2 lo2 = ldc2(flags + o + r0 + 4 * w), hi2 = ldc2(flags + o + r0 + 4 * w + 2);
+#ifdef SN_EMD_NOSPREAD
+            if (false) {
+#else
+            if (spread) {
+#endif
+              const int wsh = 31 - __builtin_clz((unsigned)(binsize >> 2));
+              rw = transposed_bin(p0 + (w >> wsh)) * binsize + 4 * (w & ((1 << wsh) - 1));
+            }
+            const int2 lo2 = ldc2(flags + o + rw), hi2 = ldc2(flags + o + rw + 2);
             f = make_int4(lo2.x, lo2.y, hi2.x, hi2.y);
-            if (f.x | f.y) stc2(loc, flags + o + r0 + 4 * w, 0, 0);
-            if (f.z | f.w) stc2(loc, flags + o + r0 + 4 * w + 2, 0, 0);
+            if (f.x | f.y) stc2(loc, flags + o + rw, 0, 0);
+            if (f.z | f.w) stc2(loc, flags + o + rw + 2, 0, 0);
           }
           const int cnt = (f.x != 0) + (f.y != 0) + (f.z != 0) + (f.w != 0);
           int incl = cnt;
@@ -1824,14 +1783,13 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
             total += wsum[wv];
           }
           if (cnt > 0) {
-            const int r = r0 + 4 * w;
+            const int r = rw;
             // the list entry also waits in the slot's (still unused) stash for bid_scan: one round trip less
             auto put = [&](int j, int rr) {
               stc2(loc, &llist[2 * pos], j, rr);
               if (pos < kStash) {
                 stash[pos].tgt = j;
                 stash[pos].rank = rr;
-                stash[pos].next = kStashOpen;  // until this workgroup emits the slot's bid itself
               }
               ++pos;
             };
@@ -1858,98 +1816,32 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
 #ifdef SN_BID_STAMPS
         c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
 #endif
-        // outbid-skip: for eps >= 0, not in the last iteration, when the previous iteration's award phase met long
-        // lists (or skipped many bidders itself: with the skip on the lists are short, so the skip count keeps it on)
-        c.A.skip = (a.eps >= 0.f && !last && (a.skip_mode == 2 || (a.skip_mode == 1 && tsd && (unsigned)s_range[3] == stamp))) ? 1 : 0;
-        // Which bid form.  Sparse bidders go to the scan (SN_EMD_SCAN_MAX); so does EVERY iteration of a contested
-        // auction (the team's `cont` word = c.A.skip, the same for every workgroup of the team): hundreds of far
-        // bidders per near target are the data on which the matrix-core search finds most pairs "near" and pays for
-        // each hit in its queue -- the refine stages of an untrained generator at 32 clouds: 56.7 -> 29.7 ms per call
-        // with the scan throughout, uniform clouds 2.45 -> 2.57 (profiles/r05_a_emd_knobs.txt).
-        const int scan_max = (c.A.skip && a.scan_max > 0 && a.scan_max < kScanContested) ? kScanContested : a.scan_max;
-        const bool scan = scan_ok && Um <= scan_max;  // uniform in the workgroup
-        const int ngroups = (Um + 63) >> 6;
-        int S = 1;
-        while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
-        // Work units ("chunks"): a wave's share of a scan pass, or a group of 64 bidders.  With S > 1 (few groups:
-        // S waves share one, the workgroup walks its groups in step) the schedule is fixed; otherwise a wave serves
-        // chunk `wave` first and takes further ones from the workgroup's cursor -- and, when its own list is done,
-        // from other workgroups of the team (TeamSteal).  ONE call site per bid form: the bodies are large.
-        const bool coop = !scan && S > 1;
-        const int gpb = kBidWaves / S;
-        const int seg = coop ? (wave & (S - 1)) : 0, gslot = coop ? wave / S : wave;
-        const int nchunks = scan ? scan_chunks(Um) : ngroups;
-        const bool shared = !coop && tsd && nchunks > kBidWaves && Um < (1 << 20);  // uniform in the workgroup
-        if (shared) {  // publish the list: every entry must have reached the L2 first
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tid == 0)
-            stc64(loc, &tsd->pub[cur][m],
-                  ((unsigned long long)stamp << 40) | ((unsigned long long)(unsigned)Um << 20) | (unsigned long long)(unsigned)r0);
-        }
-        auto take = [&](unsigned *cursor) {  // the next chunk index beyond the static ones
-          unsigned v = 0;
-          if (lane == 0) v = __hip_atomic_fetch_add(cursor, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          return kBidWaves + __builtin_amdgcn_readfirstlane((int)v);
-        };
-        // (a published list holds more than kBidWaves chunks: with U bidders over G workgroups that takes U > ~64 G)
-        const bool look = !coop && tsd && (a.steal_mode == 2 || (a.steal_mode == 1 && L.s_wait > kStealWaitPolls &&
-                                                                  (!scan || 2 * U > kQuarters * G)));
-        // the list being served: this workgroup's own one first
-        const int *w_lst = llist;
-        int w_count = Um, w_n = coop ? ngroups : nchunks;
-        bool w_scan = scan, w_local = true;
-        unsigned *w_cursor = shared ? &tsd->cur[cur][m] : nullptr;
-        int chunk = coop ? gslot : wave;
-        for (;;) {
-          if (coop) {
-            if (chunk - gslot >= ngroups) break;  // q0 = chunk - gslot runs over the rounds: every wave the same number of calls
-          } else if (chunk >= w_n) {
-            if (!look) break;
-            // Another workgroup's list.  Every wave looks on its own: lane l reads member l's words.
-            int left = 0, vcount = 0, vr0 = 0, vn = 0;
-            if (lane < G && lane != m) {
-              const unsigned long long w = ldc64(&tsd->pub[cur][lane]);
-              const int taken = ldc(reinterpret_cast<const int *>(&tsd->cur[cur][lane]));
-              if ((unsigned)(w >> 40) == stamp) {
-                vcount = (int)((w >> 20) & 0xfffffu);
-                vr0 = (int)(w & 0xfffffu);
-                vn = (scan_ok && vcount <= scan_max) ? scan_chunks(vcount) : (vcount + 63) >> 6;
-                left = vn - kBidWaves - taken;
-              }
-            }
-            int key = left > 0 ? (left << 6) | lane : 0;  // the member with most chunks left
-            for (int d = 1; d < 64; d <<= 1) {
-              const int o2 = __shfl_xor(key, d);
-              key = o2 > key ? o2 : key;
-            }
-            key = __builtin_amdgcn_readfirstlane(key);
-            if (key == 0) break;
-            const int v = key & 63;
-            w_count = __builtin_amdgcn_readlane(vcount, v);
-            w_n = __builtin_amdgcn_readlane(vn, v);
-            w_lst = llist_all + 2 * (o + __builtin_amdgcn_readlane(vr0, v));
-            w_scan = scan_ok && w_count <= scan_max;
-            w_local = false;
-            w_cursor = &tsd->cur[cur][v];
-            chunk = take(w_cursor);
-            continue;
-          }
-          if (w_scan)
-            bid_scan(c, L.scan, w_lst, w_count, chunk, w_local, wave, lane);
-          else
-            bid_group(c, tabs[wave], gacc[gslot], w_lst, w_count, chunk, (w_count + 63) >> 6, coop ? S : 1, seg, lane, w_local);
-          if (coop) {
-            chunk += gpb;
-            if (chunk - gslot < ngroups) __syncthreads();
-          } else {
-            chunk = w_cursor ? take(w_cursor) : chunk + kBidWaves;
+        // A CONTESTED auction (the team's `cont` word, read at the top: the same answer in every workgroup) or a
+        // prediction that lies OFF the targets (`far`, from the seed kernel): hundreds of far bidders per near target
+        // are the data on which the matrix-core search finds most pairs "near" and pays for every hit in its queue,
+        // so every workgroup bids with the scan -- the refine stages of an untrained generator at 32 clouds: 56.7 ->
+        // 29.7 ms per call, uniform clouds 2.45 -> 2.57 (profiles/r05_a_emd_handoff_not_kept.txt, SN_EMD_SCAN=2048) --
+        // and a contested iteration's bidders check the target's maximum before they link themselves (emit_bid).
+        c.A.skip = contested ? 1 : 0;
+        c.offsurf = contested || far;
+        const int scan_max = ((contested || far) && a.scan_max > 0 && a.scan_max < kScanContested) ? kScanContested : a.scan_max;
+        if (scan_ok && Um <= scan_max) {  // uniform in the workgroup: a quarter wave per bidder
+          bid_scan(c, L.scan, llist, Um, wave, lane);
+        } else {
+          const int ngroups = (Um + 63) >> 6;
+          int S = 1;
+          while (S < kBidWaves && S * 2 * ngroups <= kBidWaves) S *= 2;
+          const int gpb = kBidWaves / S;
+          const int seg = wave & (S - 1), gslot = wave / S;
+          for (int q0 = 0; q0 < ngroups; q0 += gpb) {
+            bid_group(c, tabs[wave], gacc[gslot], llist, Um, q0 + gslot, ngroups, S, seg, lane);
+            if (q0 + gpb < ngroups) __syncthreads();
           }
         }
       }
       if (a.diag) __syncthreads();
       tick(6);
-      if (!team_barrier(ts, &s_flag, &L.s_wait)) {
+      if (!team_barrier(ts, &s_flag)) {
         bail(b);
         return;
       }
@@ -1975,14 +1867,12 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         const int *rec = a.ws.rec + 2 * o;
         for (int u = tid; u < Um; u += kBidThreads) {
           int tgt, rank, inc_bits, nxt;
-          const bool own = u < kStash && stash[u].next != kStashOpen;  // this workgroup emitted the slot's bid itself
-          if (own) {
+          if (u < kStash) {
             const BidStash sb = stash[u];
             tgt = sb.tgt;
             rank = sb.rank;
             inc_bits = sb.inc_bits;
             nxt = sb.next;
-            if (tgt == kStashDone) continue;  // re-flagged itself on arrival (emit_bid)
           } else {
             const int2 jr = ldc2(&llist[2 * u]);
             tgt = ldc(&bo.bid[o + jr.x]);
@@ -1993,6 +1883,11 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           }
           if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
             if (!last) raise(rank);
+            continue;
+          }
+          if (nxt == kOutbid) {  // outbid on arrival, never linked (emit_bid; not in the last iteration)
+            raise(rank);
+            atomicAdd(&L.s_skipped, 1);
             continue;
           }
           if (ldc(&bo.head[o + tgt]) != rank) continue;  // somebody else walks this target's list
@@ -2074,13 +1969,13 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
             s_bins[tid] = 0;
           }
         }
-        if (tid == kRankBins && tsd) {  // contested targets: the next iteration's bidders check the maximum before they link
+        if (tid == kRankBins) {  // contested targets: the next iteration's bidders check the maximum before they link
           // switched ON by a long list, kept on while at least half of this workgroup's bidders find themselves
           // outbid on arrival (with the skip on the lists are short, so the walkers no longer see the contention);
           // uniform clouds: 20-30 % in the early iterations -- there the second round trip per bid costs 1.6 us per
           // iteration and buys nothing
           if (L.s_long || (L.s_skipped >= 16 && 2 * L.s_skipped >= Um))
-            stc(loc, reinterpret_cast<int *>(&tsd->cont[cur ^ 1]), (int)((stamp + 1u) & 0xffffffu));
+            stc(loc, reinterpret_cast<int *>(&note[cur ^ 1]), (int)((stamp + 1u) & 0xffffffu));
           L.s_long = 0;
           L.s_skipped = 0;
         }
@@ -2142,8 +2037,7 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
 
 constexpr size_t kDiagWords = 16 + 64 * 64;                        // int64 phase timers (SN_EMD_DIAG)
 constexpr size_t kCtlWords = 32 + 32 * 1024;                        // ticket, abort, up to 1024 team counters
-constexpr size_t kStealBytes = 1024 * sizeof(TeamSteal);         // one TeamSteal per team
-constexpr size_t kCtlBytes = 4 * kCtlWords + kStealBytes + 8 * kDiagWords;
+constexpr size_t kCtlBytes = 4 * kCtlWords + 8 * kDiagWords;
 
 EmdWs carve(void *workspace, int b, int n) {
   char *p = static_cast<char *>(workspace);
@@ -2176,6 +2070,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.flags = reinterpret_cast<int *>(p); p += arr;
   ws.hist1 = reinterpret_cast<int *>(p); p += (size_t)b * kSortCells * 4;
   ws.bbox1 = reinterpret_cast<float *>(p); p += sn::align_up((size_t)b * 24, 256);
+  ws.far = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * 4, 256);
   ws.ctl = p; p += kCtlBytes;
   return ws;
 }
@@ -2385,7 +2280,7 @@ extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   return 14 * sn::align_up((size_t)b * n * 4, 256) + 3 * sn::align_up((size_t)b * n * 8, 256) +
          2 * sn::align_up((size_t)b * kRankBins * 4, 256) + 2 * sn::align_up((size_t)b * n * 16, 256) +
          2 * (size_t)b * kSortCells * 4 + 2 * sn::align_up((size_t)b * 24, 256) +
-         sn::align_up((size_t)b * (n / 16) * 32, 256) + kCtlBytes;
+         sn::align_up((size_t)b * (n / 16) * 32, 256) + sn::align_up((size_t)b * 4, 256) + kCtlBytes;
 }
 
 // byte offset of the diagnostic words (SN_EMD_DIAG) inside the workspace
@@ -2475,15 +2370,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   static const bool check = [] { const char *e = getenv("SN_EMD_CHECK"); return e && e[0] == '1'; }();
   emd_init_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz2, assignment, ws);
   emd_sbbox_kernel<<<(int)(((long)b * (n / 64) + 3) / 4), 256, 0, s>>>(b, n, xyz2, ws);
-  {
-    // SN_EMD_SEED=window: rounds 1-4's seeds (A/B, tools/emd_regimes.py); read per call
-    const char *e = getenv("SN_EMD_SEED");
-    const bool window = (n >> 4) > kSeedBlk || (e && e[0] == 'w');
-    if (window)
-      emd_seed_window_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
-    else
-      emd_seed_kernel<<<b * (n / kSeedThreads), kSeedThreads, 0, s>>>(b, n, xyz1, ws);
-  }
+  emd_seed_kernel<<<eblocks, kThreads, 0, s>>>(b, n, xyz1, xyz2, ws);
   {
     // one workgroup of 16 waves per CU (the register budget admits exactly one): the whole grid is resident
     // on an idle device, and the ticket order keeps it live next to other launches (see the kernel's header)
@@ -2511,21 +2398,20 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     }
     args.tg = team_geometry(b, cus * kWgPerCu, gmax, legacy);
     args.diag = diag;
+    static const int diag_m0 = [] { const char *e = getenv("SN_EMD_DIAG_M0"); return e ? atoi(e) : 0; }();
+    args.diag_m0 = diag_m0;
     static const unsigned spin_env = [] { const char *e = getenv("SN_EMD_SPIN_LIMIT"); return e ? (unsigned)atol(e) : 0u; }();
     args.spin_limit = (diag & 8) ? (1u << 15) : (spin_env ? spin_env : kSpinLimit);   // SN_EMD_SPIN_LIMIT: debugging aid
-    args.steal = reinterpret_cast<TeamSteal *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
-    args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords + kStealBytes);
+    args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
     {  // read per call: the tests compare the settings inside one process
-      const char *e = getenv("SN_EMD_STEAL");
-      args.steal_mode = e ? atoi(e) : 1;
-      if (args.steal_mode < 0) args.steal = nullptr;  // no steal area at all: fixed strides, no outbid-skip feedback
-      e = getenv("SN_EMD_SKIP");
+      const char *e = getenv("SN_EMD_SKIP");
       args.skip_mode = e ? atoi(e) : 1;
+      e = getenv("SN_EMD_SPREAD");
+      args.spread_mode = e ? atoi(e) : 1;
     }
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
     SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
-    SN_HIP(hipMemsetAsync(args.steal, 0, sizeof(TeamSteal) * (size_t)args.tg.teams, s));
     {
       // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
       // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.

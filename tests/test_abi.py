@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu():
     # 14 word arrays + 3 arrays of 8-byte entries (bid records, {index, rank} lists, {price, index} stream) + ...
     assert lib.sn_emd_workspace_bytes(32, 16384) == (14 * 32 * 16384 * 4 + 3 * 32 * 16384 * 8 + 2 * 32 * 256 * 4
                                                       + 2 * 32 * 16384 * 16 + 2 * 32 * 4096 * 4 + 2 * 768
-                                                      + 32 * 1024 * 32 + ctl)
+                                                      + 32 * 1024 * 32 + 256 + ctl)   # ... + the far-bidder counters
 
 
 def test_no_cpu_fallback_anywhere():

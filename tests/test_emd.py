@@ -162,6 +162,43 @@ def test_hip_both_bid_paths_match_oracle(scan, dev, monkeypatch):
         assert np.array_equal(d0, d1), (scan, b, n, iters, kind)
 
 
+def _contested(b, n, seed, spread=1.0):
+    """Targets on a sphere of radius 0.5, bidders scattered through a cube of half-width `spread` around it: the bidders
+    outside the sphere all prefer the near-side targets -- hundreds of bidders per target, prices that keep climbing,
+    an auction that does not converge in 50 iterations (what the refine stages of an untrained generator produce)."""
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(b, n, 3, generator=g)
+    y = 0.5 * y / y.norm(dim=2, keepdim=True)
+    x = y + spread * (2 * torch.rand(b, n, 3, generator=g) - 1)
+    return x.contiguous().numpy(), y.contiguous().numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("skip,spread", [("1", "1"), ("2", "2"), ("0", "3"), ("2", "0")])
+def test_hip_contested_auction_paths_match_oracle(skip, spread, dev, monkeypatch):
+    """Round 5's data-dependent paths, each forced on and off (read per call): the outbid-skip (SN_EMD_SKIP: a bidder
+    that finds its target's running maximum already above its own increment + 1e-6 does not link itself; 2 = in every
+    iteration, 1 = when the previous iteration's lists say so), the transposed rank split of scan iterations
+    (SN_EMD_SPREAD: 2 = every iteration, 3 = every scan iteration, 1 = off-surface / contested clouds) and, through
+    them, the scan for every workgroup of a contested iteration.  Contested clouds (lists of hundreds), ties, negative
+    eps (no skip: prices fall, the persistent max_idx can decide), one iteration (the forced last one), team
+    geometries from one workgroup per cloud (b = 40) to a whole XCD (b = 2)."""
+    monkeypatch.setenv("SN_EMD_SKIP", skip)
+    monkeypatch.setenv("SN_EMD_SPREAD", spread)
+    cases = [("contested", 2, 2048, 12, 0.005, 21), ("contested", 9, 1024, 25, 0.005, 22),
+             ("contested", 40, 1024, 6, 0.002, 23), ("contested", 1, 4096, 50, 0.005, 24),
+             ("contested", 3, 1024, 1, 0.005, 25), ("contested", 2, 1024, 9, -0.001, 26),
+             ("lattice", 2, 1024, 6, 0.005, 5), ("near", 2, 1024, 15, 0.005, 4), ("uniform", 9, 1024, 20, 0.005, 9),
+             ("clustered", 1, 8192, 6, 0.005, 11), ("contested", 1, 3072, 8, 0.005, 27)]
+    for kind, b, n, iters, eps, seed in cases:
+        x, y = _contested(b, n, seed) if kind == "contested" else _clouds(b, n, seed, kind)
+        d0, a0, aux = oracle.emd_forward(x, y, eps, iters, mt=True, return_aux=True)
+        d1, a1, st = _hip(x, y, eps, iters, dev, stats=True)
+        assert np.array_equal(a0, a1), (skip, spread, kind, b, n, iters)
+        assert np.array_equal(d0, d1), (skip, spread, kind, b, n, iters)
+        assert int(st[0]) == aux["pairs_eff"], (skip, spread, kind, b, n, iters)
+
+
 @pytest.mark.gpu
 def test_hip_prices_bit_exact_when_converged(dev):
     """Sensitive arithmetic check: when the auction converges before the last

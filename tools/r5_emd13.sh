@@ -1,0 +1,17 @@
+#!/bin/bash
+cd "$(dirname "$0")/.."
+R=$GRAFT_REPO_ROOT
+O=gpurun_out/r5_emd13; mkdir -p $O
+export TMPDIR=/tmp
+for v in r4 new alloff sync; do
+  if [ $v = r4 ]; then export AB_LIB=$R/tools/ab/lib_r4.so; elif [ $v = new ]; then unset AB_LIB; else export AB_LIB=$R/tools/ab/lib_$v.so; fi
+  (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$v -- python $R/tools/emd_regimes.py uniform surface > /tmp/log_$v.txt 2>&1)
+  f=$(find /tmp/prof_$v -name "*kernel_stats.csv" | head -1)
+  echo "== $v"; grep regime /tmp/log_$v.txt; python - <<PY
+import csv
+rows = list(csv.reader(open("$f")))
+for r in rows[1:6]:
+    print(f"{r[1]:>6} {float(r[2])/1e6:9.3f} {float(r[3])/1e3:9.1f} {float(r[4]):6.2f}  {r[0][:60]}")
+PY
+done > $O/kstats.txt 2>&1
+cat $O/kstats.txt
