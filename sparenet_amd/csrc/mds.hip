@@ -42,6 +42,18 @@
 #define SN_MDS_LAZY 0
 #endif
 
+#ifdef SN_MDS_STATS   // experiment builds: how many picks the multi-pick rounds of cloud 0 took (histogram by picks per round)
+__device__ unsigned long long g_mds_rounds[8];
+extern "C" int sn_mds_debug_rounds(unsigned long long *out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mds_rounds), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mds_rounds), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
+
 namespace {
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m, int width) {
@@ -584,6 +596,12 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
           }
         }
       }
+#ifdef SN_MDS_STATS
+      if (tid == 0 && b == 0) {
+        atomicAdd(&g_mds_rounds[npick], 1ull);
+        atomicAdd(&g_mds_rounds[5], (unsigned long long)valid);
+      }
+#endif
       if (tid == 0)
         for (int r = 0; r < npick; ++r) {
           const int sl = r == 0 ? sel[0] : (r == 1 ? sel[1 < K ? 1 : 0] : (r == 2 ? sel[2 < K ? 2 : 0] : sel[K - 1]));
