@@ -6,12 +6,24 @@ meaning as /root/reference/cuda/* and utils/p2i_utils.py); every op calls the
 hand-written HIP kernels in libsparenet_hip.so through the C ABI declared in
 include/sparenet_hip.h.  There is no CPU or eager-PyTorch fallback.
 """
-from ._lib import LIB_PATH, SparenetHipError, lib  # noqa: F401
+from ._lib import LIB_PATH, SparenetHipError, device_check, lib  # noqa: F401
 
 __version__ = "0.1.0"
 
 _REFERENCE_OP_PACKAGES = ("chamfer_distance", "chamfer_dist", "emd", "expansion_penalty", "MDS", "p2i_op",
                           "gridding", "gridding_loss", "cubic_feature_sampling")
+
+
+def loss_item(loss):
+    """`loss.item()` that cannot hand back the number of a failed step: the host waits for the GPU (as `.item()` always
+    does), then the device's sticky error word is read (sn_device_status) -- if a team barrier of the persistent EMD
+    auction or of the density sampler timed out in any launch up to here (a shared device, a debugger holding a compute
+    unit), its outputs were NaN / -1 and this raises SparenetHipError instead of returning NaN to the training loop.
+    Where the reference's runners log `_loss.item()` every step (runners/sparenet_runner.py:113-116), log
+    `sparenet_amd.loss_item(_loss)` -- before `optimizer.step()` if a failed step must not touch the weights."""
+    value = loss.item()
+    device_check("loss_item")
+    return value
 
 
 def alias_reference_modules():

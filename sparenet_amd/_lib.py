@@ -86,6 +86,15 @@ def check(code, what):
         raise SparenetHipError(f"{what} failed (code {code}): {msg}")
 
 
+def device_check(what="sparenet_amd"):
+    """Raise if a bounded wait inside an EARLIER multi-workgroup launch on the current device gave up (the persistent EMD
+    auction's team barriers, the density sampler's teams; that call's outputs are NaN / -1).  Reads one word of pinned
+    host memory (sn_device_status): no synchronisation -- meaningful for work that has FINISHED, so the wrappers call
+    it on entry (an earlier step's failure surfaces at the next op) and `loss_item` calls it where the host has just
+    waited for the loss."""
+    check(lib().sn_device_status(), what)
+
+
 def ptr(t, dtype, name):
     """Device pointer of a contiguous CUDA tensor (validated)."""
     if not isinstance(t, torch.Tensor):

@@ -54,6 +54,8 @@ class emdFunction(Function):
 
         xyz1 = xyz1.contiguous().float()
         xyz2 = xyz2.contiguous().float()
+        # (an EARLIER launch's team time-out fails this call inside the library -- sn_emd_forward checks the device's
+        # sticky word first; a time-out of THIS launch surfaces at the next op or at sparenet_amd.loss_item)
         dist, assignment = emd_forward_raw(xyz1, xyz2, eps, iters)
         ctx.save_for_backward(xyz1, xyz2, assignment)
         ctx.mark_non_differentiable(assignment)

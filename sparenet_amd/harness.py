@@ -34,6 +34,7 @@ import random
 
 import torch
 
+from sparenet_amd import _lib
 from sparenet_amd.utils.p2i_utils import N_VIEWS_PREDEFINED, ComputeDepthMaps
 
 from sparenet_amd.cuda.chamfer_distance import ChamferDistance, ChamferDistanceMean
@@ -94,9 +95,12 @@ class SurrogateGenerator(torch.nn.Module):
 class Completion(torch.nn.Module):
     """runners/sparenet_runner.py:67-108."""
 
-    def __init__(self, metric="chamfer", use_consist_loss=True, overlap=True):
+    def __init__(self, metric="chamfer", use_consist_loss=True, overlap=True, batch_terms=True):
+        """overlap: Chamfer metric only -- the loss of a finished cloud on a second stream while the next refine stage
+        samples (no effect with the EMD metric, see forward); batch_terms: EMD metric -- the three terms through one
+        auction call (see _metrics)."""
         super().__init__()
-        self.overlap, self._side = overlap, None
+        self.overlap, self._side, self.batch_terms = overlap, None, batch_terms
         if metric not in ("chamfer", "emd"):
             raise Exception("unknown training metric")
         self.metric, self.use_consist_loss = metric, use_consist_loss
@@ -110,17 +114,34 @@ class Completion(torch.nn.Module):
         dist, _ = self.emd_dist(cloud, gt, eps=0.005, iters=50)
         return emd_term(dist)
 
+    def _metrics(self, clouds, gt):
+        """The metric of every cloud set against `gt`, one value per set.  EMD: the sets go through ONE auction call
+        as a batch of len(clouds) x B clouds (the three terms of runners/sparenet_runner.py:91-93 feed one loss; every
+        cloud of the batch is its own auction, so dist / assignment / gradients are those of the separate calls bit
+        for bit) -- one persistent launch instead of three: 3 x 1.06 ms -> 1.3 ms at 4 clouds per rank on a trained
+        generator's clouds, 3 x 8.0 -> ~12 ms on an untrained one's."""
+        if self.metric == "chamfer" or len(clouds) == 1 or not self.batch_terms:
+            return [self._metric(c, gt) for c in clouds]
+        b = gt.shape[0]
+        dist, _ = self.emd_dist(torch.cat(clouds, 0), gt.repeat(len(clouds), 1, 1), eps=0.005, iters=50)
+        return [emd_term(dist[i * b:(i + 1) * b]) for i in range(len(clouds))]
+
     def forward(self, generator, partial, gt):
-        # any generator that can hand its clouds over as they become final (SurrogateGenerator, networks.Generator;
-        # a DistributedDataParallel wrapper hides the method on purpose: its forward hooks must run).  Chamfer metric
-        # only: the EMD auction is one persistent launch that needs EVERY compute unit (a team of 32 workgroups per
-        # XCD), so beside the sampler -- one workgroup per cloud for ~18 ms -- its teams spin until the sampler's CUs
-        # are free: measured, rocprofv3 shows 17.7 ms per auction launch instead of 1.2 and the step does not move
-        # (config 4: 141 ms either way, profiles/r04_c_network_config4_steady.txt)
-        if self.overlap and self.metric == "chamfer" and partial.is_cuda and hasattr(generator, "forward_staged"):
+        _lib.device_check("Completion")   # a team time-out of an EARLIER step raises here, at the latest (see loss_item)
+        # Generators that can hand their clouds over as they become final (SurrogateGenerator, networks.Generator --
+        # exactly these two: calling forward_staged() goes around nn.Module.__call__, i.e. around forward hooks and
+        # wrappers such as DistributedDataParallel or torch.compile, which therefore take the plain path below).
+        # Chamfer metric only: the EMD auction is one persistent launch that needs EVERY compute unit (a team of 32
+        # workgroups per XCD), so beside the sampler -- one workgroup per cloud for ~18 ms -- its teams spin until the
+        # sampler's CUs are free: measured, rocprofv3 shows 17.7 ms per auction launch instead of 1.2 and the step
+        # does not move (config 4: 141 ms either way, profiles/r04_c_network_config4_steady.txt)
+        from sparenet_amd.networks import Generator as _NetGenerator
+        if (self.overlap and self.metric == "chamfer" and partial.is_cuda
+                and type(generator) in (SurrogateGenerator, _NetGenerator) and not generator._forward_hooks
+                and not generator._forward_pre_hooks):
             return self._forward_overlapped(generator, partial, gt)
         coarse, middle, refine, expansion_penalty = generator(partial)
-        coarse_loss, middle_loss, refine_loss = (self._metric(c, gt) for c in (coarse, middle, refine))
+        coarse_loss, middle_loss, refine_loss = self._metrics([coarse, middle, refine], gt)
         return self._compose(coarse, middle, refine, expansion_penalty, coarse_loss, middle_loss, refine_loss, gt)
 
     def _forward_overlapped(self, generator, partial, gt):
@@ -185,6 +206,7 @@ class GanStep:
                           for v in range(N_VIEWS_PREDEFINED)], dim=1)
 
     def __call__(self, partial, gt):
+        _lib.device_check("GanStep")
         batch = partial.shape[0]
         real_label = torch.ones(batch, 1, device=partial.device)
         fake_label = torch.zeros(batch, 1, device=partial.device)

@@ -362,6 +362,15 @@ def load_reference_state_dict(generator, ref_sd):
     return sorted(k for k in ref_sd if not k.startswith(used_prefixes) or ".adain" in k or "residual.bn7" in k)
 
 
+# _SpectralNormGemm below builds on a PRIVATE torch class: refuse at import, loudly, if a torch upgrade changed what it
+# relies on (the CPU test tests/test_networks.py::test_spectral_norm_gemm_equals_torch is the numeric canary).
+_SN_BASE = getattr(nn.utils.parametrizations, "_SpectralNorm", None)
+if _SN_BASE is None or not all(hasattr(_SN_BASE, a) for a in ("_power_method", "_reshape_weight_to_matrix", "forward")):
+    raise ImportError("sparenet_amd.networks: torch.nn.utils.parametrizations._SpectralNorm no longer has the methods "
+                      f"_SpectralNormGemm overrides (torch {torch.__version__}; written against 2.10) -- adapt "
+                      "_SpectralNormGemm before using the discriminators")
+
+
 class _SpectralNormGemm(nn.utils.parametrizations._SpectralNorm):
     """torch's spectral-norm parametrization (same buffers, same state_dict keys, one power iteration per training
     forward as `nn.utils.spectral_norm` in models/sparenet_discriminator.py), with the three matrix-vector products of a

@@ -387,6 +387,37 @@ print("RESULT", int(nan0), int(clean1), raised)
 
 
 @pytest.mark.gpu
+def test_loss_item_raises_after_a_team_timeout():
+    """What a training loop sees: the loss of a step whose auction timed out is NaN; `sparenet_amd.loss_item(loss)` --
+    `.item()` + sn_device_status() at the point where the host has waited for the GPU anyway -- raises instead of
+    returning it, and the next `Completion` / `GanStep` call would raise on entry as well (harness.py)."""
+    import subprocess
+    code = _SUBPROCESS_HEAD + r"""
+import sparenet_amd
+from sparenet_amd.cuda.emd.emd_module import emdModule
+from sparenet_amd.networks import emd_term
+g = torch.Generator().manual_seed(1)
+x = torch.rand(2, 1024, 3, generator=g).to(dev).requires_grad_(True)
+y = torch.rand(2, 1024, 3, generator=g).to(dev)
+dist, _ = emdModule()(x, y, eps=0.005, iters=10)
+loss = emd_term(dist)
+try:
+    v = sparenet_amd.loss_item(loss)
+    raised = 0
+except sparenet_amd.SparenetHipError as e:
+    raised = int("timed out" in str(e))
+sparenet_amd.device_check()                     # the word was cleared by the report: clean again
+print("RESULT", raised, int(bool(torch.isnan(loss))))
+"""
+    env = {k: v for k, v in os.environ.items() if k != "SN_EMD_CHECK"}
+    env["SN_EMD_DIAG"] = "8"
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
+    assert line, out.stderr[-2000:]
+    assert line[0].split()[1:] == ["1", "1"], (line, out.stderr[-1000:])
+
+
+@pytest.mark.gpu
 def test_mds_team_timeout_is_loud_without_a_sync():
     """The sampler's dense-regime teams: a member that never arrives (SN_MDS_DIAG=8 parks the second workgroup of
     cloud 0's team and shortens the polls) must not leave valid-looking indices behind.  The cloud's WHOLE index row

@@ -65,3 +65,31 @@ def test_gan_step_runs_and_reaches_the_cloud(dev):
     assert val.shape == (B, 1) and [f.shape[1] for f in feats] == [16, 32, 64, 128]
     (val.mean() + torch.nn.functional.l1_loss(imgs, real)).backward()
     assert gen.coarse.grad is not None and gen.coarse.grad.abs().sum() > 0
+
+
+@pytest.mark.gpu
+def test_batched_emd_terms_equal_the_three_calls(dev):
+    """harness.Completion with the EMD metric sends coarse / middle / refine through ONE auction call (a batch of 3 B
+    clouds against the ground truth repeated): every cloud is its own auction, so the three terms, the loss and the
+    gradients on the generator's parameters equal those of three separate calls bit for bit."""
+    from sparenet_amd.harness import Completion, SurrogateGenerator
+
+    g = torch.Generator().manual_seed(5)
+    B, N, M = 3, 2048, 384
+    v = torch.randn(B, N, 3, generator=g)
+    gt = (0.5 * v / v.norm(dim=2, keepdim=True)).to(dev)
+    partial = (gt[:, :M] + 1e-3 * torch.randn(B, M, 3, generator=g).to(dev)).contiguous()
+    init = gt.cpu() + 0.05 * torch.randn(B, N, 3, generator=g)
+    res = []
+    for batch_terms in (True, False):
+        gen = SurrogateGenerator(B, N, n_primitives=4, init=init).to(dev)
+        with torch.no_grad():
+            gen.refine1.delta.add_(0.01 * torch.randn(B, 3, N, generator=torch.Generator().manual_seed(9)).to(dev))
+        comp = Completion("emd", batch_terms=batch_terms).to(dev)
+        loss, refine, middle, coarse, refine_loss, coarse_loss = comp(gen, partial, gt)
+        loss.backward()
+        res.append((loss.detach(), refine_loss.detach(), coarse_loss.detach(),
+                    [p.grad.detach().clone() for p in gen.parameters()]))
+    (l1, r1, c1, g1), (l2, r2, c2, g2) = res
+    assert torch.equal(l1, l2) and torch.equal(r1, r2) and torch.equal(c1, c2)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))

@@ -1,14 +1,14 @@
 """Where does the HOST spend its time in one rank's share of BASELINE config 4 / 5?  (Round 4: rocprofv3 shows the GPU
 busy for 148 of config 5's 397 ms per step -- the rest is the host.)  Prints the step time, then torch.profiler's CPU
 table (self time per operator) and cProfile's view of the main thread for a few steady-state steps.
-    python tools/net_host_profile.py config5 [trained_stand_in|random_init]"""
+    python tools/net_host_profile.py config5 [trained_stand_in_damped|scattered_stand_in|random_init]"""
 import cProfile, io, os, pstats, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config5"
-state = sys.argv[2] if len(sys.argv) > 2 else "trained_stand_in"
+state = sys.argv[2] if len(sys.argv) > 2 else "trained_stand_in_damped"
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
 step = bench.make_network_step(dev, cfg, state)

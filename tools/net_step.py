@@ -1,5 +1,5 @@
 """One rank's share of BASELINE config 4 / 5 (bench.make_network_step), a few steps: the command rocprofv3 wraps to
-say where the step's time goes.   python tools/net_step.py config4|config5 [random_init|trained_stand_in] [steps]
+say where the step's time goes.   python tools/net_step.py config4|config5 [random_init|scattered_stand_in|trained_stand_in_damped] [steps]
 NS_OVERLAP=0 turns the loss / sampler overlap off."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,11 +7,11 @@ import torch
 import bench
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config4"
-state = sys.argv[2] if len(sys.argv) > 2 else "trained_stand_in"
+state = sys.argv[2] if len(sys.argv) > 2 else "trained_stand_in_damped"
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 dev = torch.device("cuda:0")
 torch.cuda.set_device(dev)
-step = bench.make_network_step(dev, cfg, state, overlap=os.environ.get("NS_OVERLAP", "1") == "1")
+step = bench.make_network_step(dev, cfg, state, batch_terms=os.environ.get("NS_BATCH_TERMS", "1") == "1")
 for _ in range(int(os.environ.get("NS_WARMUP", "2"))):
     step()
 torch.cuda.synchronize()
