@@ -242,7 +242,8 @@ struct EmdWs {
   int *assignment_inv;
   float *price;
   int *bid, *bid2;
-  int *rec;      // [B, n, 2] by bidder RANK: {bid increment bits, rank of the next bidder of the same target or -1}
+  int *rec;      // [B, n, 4] by bidder RANK: {bid increment bits, rank of the next bidder of the same target or -1,
+                 //  bidder index, -}: one 16-byte line segment per step of the award phase's walk
   float *max_inc;
   int *max_idx;  // GetMax's winner per target (as a bidder RANK); PERSISTS across iterations like the reference's tensor
   int *head;     // [B, n] per target: rank of the bidder that pushed last in this iteration's bid phase, -1: no bid
@@ -281,7 +282,9 @@ __global__ void emd_init_kernel(int B, int n, const float *__restrict__ xyz2,
     ws.bid[e] = -1;   // no previous favourites yet (filter seeding)
     ws.bid2[e] = -1;
     ws.rank1[e - e % n + ws.perm1[e]] = (int)(e % n);  // max_idx: see emd_seed_kernel (needs rank1 complete)
-    ws.flags[e] = 1;  // every bidder starts flagged (= unassigned)
+    // every bidder starts flagged (= unassigned).  A raised flag IS the bidder's index + 1 (by rank): the compaction
+    // builds its {index, rank} list from the flag words alone, without a dependent look-up in perm1
+    ws.flags[e] = ws.perm1[e] + 1;
     ws.prt[e] = 0.f;
     {  // stream position p of this cloud holds target k = tperm[p]
       const long bb = e / n;
@@ -447,7 +450,7 @@ constexpr int kStash = kBidThreads;  // list slots whose bid is handed to the aw
 // next == kOutbid (also in rec[rank].next): the bidder found itself outbid on arrival and did not link itself
 // (emit_bid): the award phase only re-flags it.
 struct BidStash {
-  int tgt, rank, inc_bits, next;
+  int tgt, rank, inc_bits, next, j;
 };
 constexpr int kOutbid = -3;
 
@@ -477,8 +480,9 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int r
   if (top.best_i < 0) {  // only with non-finite coordinates: no comparison succeeded
     stc(loc, &A.bid[o + j], -1);
     stc(loc, &A.bid2[o + j], -1);
-    stc2(loc, &A.rec[2 * (o + rank)], 0, -1);
-    if (st) stash[u] = BidStash{-1, rank, 0, -1};
+    stc2(loc, &A.rec[4 * (o + rank)], 0, -1);
+    stc(loc, &A.rec[4 * (o + rank) + 2], j);
+    if (st) stash[u] = BidStash{-1, rank, 0, -1, j};
     return;
   }
   const float inc = (top.best - top.better) + eps;
@@ -491,8 +495,9 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int r
 #endif
     const float before = atomic_max_float_old(&A.max_inc[o + top.best_i], inc);
     if ((double)before > (double)inc + 1e-6) {  // outbid already: stays unassigned, bids again
-      stc2(loc, &A.rec[2 * (o + rank)], __float_as_int(inc), kOutbid);
-      if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), kOutbid};
+      stc2(loc, &A.rec[4 * (o + rank)], __float_as_int(inc), kOutbid);
+      stc(loc, &A.rec[4 * (o + rank) + 2], j);
+      if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), kOutbid, j};
       return;
     }
   } else {
@@ -500,8 +505,9 @@ __device__ __forceinline__ void emit_bid(const BidOut &A, size_t o, int j, int r
   }
   const int prev = (int)__hip_atomic_exchange(reinterpret_cast<unsigned *>(&A.head[o + top.best_i]), (unsigned)rank,
                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  stc2(loc, &A.rec[2 * (o + rank)], __float_as_int(inc), prev);
-  if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), prev};
+  stc2(loc, &A.rec[4 * (o + rank)], __float_as_int(inc), prev);
+  stc(loc, &A.rec[4 * (o + rank) + 2], j);  // the bidder's index travels with its rank: no perm1 look-up in the award phase
+  if (st) stash[u] = BidStash{top.best_i, rank, __float_as_int(inc), prev, j};
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1594,7 +1600,6 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
     c.sbb = a.ws.sbbox + (size_t)b * nsb * 32;
     c.A = bo;
     c.stash = stash;
-    const int *perm1 = a.ws.perm1 + o;
     // stamps grow from cloud to cloud and from iteration to iteration: a word left by an earlier cloud or iteration
     // never looks like this iteration's
     const unsigned stamp0 = (unsigned)cloud_seq * (unsigned)(a.iters + 1);
@@ -1793,10 +1798,10 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
               }
               ++pos;
             };
-            if (f.x) put(perm1[r], r);
-            if (f.y) put(perm1[r + 1], r + 1);
-            if (f.z) put(perm1[r + 2], r + 2);
-            if (f.w) put(perm1[r + 3], r + 3);
+            if (f.x) put(f.x - 1, r);
+            if (f.y) put(f.y - 1, r + 1);
+            if (f.z) put(f.z - 1, r + 2);
+            if (f.w) put(f.w - 1, r + 3);
           }
           base += total;
           __syncthreads();
@@ -1860,75 +1865,78 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
       // the barrier (lists, increments) or belongs to its target alone.
       {
         unsigned *nextbins = reinterpret_cast<unsigned *>(a.ws.bins[cur ^ 1] + b * kRankBins);
-        auto raise = [&](int rank) {  // counted per bin in LDS first: <= 256 device atomics per workgroup
-          stc(loc, &flags[o + rank], 1);
+        auto raise = [&](int rank, int j) {  // the flag is the bidder's index + 1; counted per bin in LDS first
+          stc(loc, &flags[o + rank], j + 1);
           atomicAdd(&s_bins[rank / binsize], 1);
         };
-        const int *rec = a.ws.rec + 2 * o;
+        const int *rec = a.ws.rec + 4 * o;
         for (int u = tid; u < Um; u += kBidThreads) {
-          int tgt, rank, inc_bits, nxt;
+          int tgt, rank, inc_bits, nxt, jown;
           if (u < kStash) {
             const BidStash sb = stash[u];
             tgt = sb.tgt;
             rank = sb.rank;
             inc_bits = sb.inc_bits;
             nxt = sb.next;
+            jown = sb.j;
           } else {
             const int2 jr = ldc2(&llist[2 * u]);
             tgt = ldc(&bo.bid[o + jr.x]);
             rank = jr.y;
-            const int2 r2 = ldc2(&rec[2 * rank]);
+            jown = jr.x;
+            const int2 r2 = ldc2(&rec[4 * rank]);
             inc_bits = r2.x;
             nxt = r2.y;
           }
           if (tgt < 0) {  // no bid (non-finite input): stays unassigned, distance 0, zero gradient
-            if (!last) raise(rank);
+            if (!last) raise(rank, jown);
             continue;
           }
           if (nxt == kOutbid) {  // outbid on arrival, never linked (emit_bid; not in the last iteration)
-            raise(rank);
+            raise(rank, jown);
             atomicAdd(&L.s_skipped, 1);
             continue;
           }
-          if (ldc(&bo.head[o + tgt]) != rank) continue;  // somebody else walks this target's list
-          // the four words of the target, requested together
+          // the list's head and the four words of the target, requested TOGETHER: most targets have one bidder, which
+          // is then the head and needs them -- one round trip instead of two on the award phase's chain
+          const int hd = ldc(&bo.head[o + tgt]);
           const float mi = ldc(&bo.max_inc[o + tgt]);
           const int wp = ldc(&a.ws.max_idx[o + tgt]);
           const int inv = ldc(&a.ws.assignment_inv[o + tgt]);
           const float pr = ldc(&price[o + tgt]);
-          int w_rank = -1, w_j = -1, p_inc = 0;
+          if (hd != rank) continue;  // somebody else walks this target's list
+          int w_rank = -1, w_j = -1, p_inc = 0, p_j = -1;
           float w_inc = 0.f;
           bool persist_hit = false;
           int steps = 0;
-          for (int cr = rank, ci = inc_bits, cn = nxt;; ++steps) {
+          for (int cr = rank, ci = inc_bits, cn = nxt, cj = jown;; ++steps) {
             const float bi = __int_as_float(ci);
             if (last) {  // forced assignment (:200): every bidder takes its target; prices still accumulate (:209)
-              stc(loc, &a.assignment[o + perm1[cr]], tgt);
+              stc(loc, &a.assignment[o + cj], tgt);
               w_inc += bi;  // several claimants: a race in the reference, list order here
             } else if ((double)bi - 1e-6 <= (double)mi && (double)mi <= (double)bi + 1e-6) {
               if (w_rank < 0) {
                 w_rank = cr;
+                w_j = cj;
                 w_inc = bi;
-              } else {  // several bidders inside the window: the highest bidder INDEX wins
-                if (w_j < 0) w_j = perm1[w_rank];
-                const int jc = perm1[cr];
-                if (jc > w_j) {
-                  raise(w_rank);
-                  w_rank = cr;
-                  w_j = jc;
-                  w_inc = bi;
-                } else {
-                  raise(cr);
-                }
+              } else if (cj > w_j) {  // several bidders inside the window: the highest bidder INDEX wins
+                raise(w_rank, w_j);
+                w_rank = cr;
+                w_j = cj;
+                w_inc = bi;
+              } else {
+                raise(cr, cj);
               }
             } else if (cr == wp) {  // outside the window, but the persistent winner: decided after the walk
               persist_hit = true;
               p_inc = ci;
+              p_j = cj;
             } else {
-              raise(cr);
+              raise(cr, cj);
             }
             if (cn < 0) break;
-            const int2 r2 = ldc2(&rec[2 * cn]);
+            const int2 r2 = ldc2(&rec[4 * cn]);  // {increment, next} and the index: one line segment, one round trip
+            cj = ldc(&rec[4 * cn + 2]);
             cr = cn;
             ci = r2.x;
             cn = r2.y;
@@ -1941,16 +1949,16 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           }
           if (w_rank >= 0) {
             stc(loc, &a.ws.max_idx[o + tgt], w_rank);
-            if (persist_hit) raise(wp);
+            if (persist_hit) raise(wp, p_j);
           } else if (persist_hit) {
             w_rank = wp;
+            w_j = p_j;
             w_inc = __int_as_float(p_inc);
           }
           if (w_rank < 0) continue;  // nobody wins this target in this iteration
-          if (w_j < 0) w_j = perm1[w_rank];
           if (inv != -1) {
             stc(loc, &a.assignment[o + inv], -1);
-            raise(a.ws.rank1[o + inv]);  // evicted: bids again
+            raise(a.ws.rank1[o + inv], inv);  // evicted: bids again
           }
           stc(loc, &a.ws.assignment_inv[o + tgt], w_j);
           stc(loc, &a.assignment[o + w_j], tgt);
@@ -2048,7 +2056,7 @@ EmdWs carve(void *workspace, int b, int n) {
   ws.price = reinterpret_cast<float *>(p); p += arr;
   ws.bid = reinterpret_cast<int *>(p); p += arr;
   ws.bid2 = reinterpret_cast<int *>(p); p += arr;
-  ws.rec = reinterpret_cast<int *>(p); p += arr2;
+  ws.rec = reinterpret_cast<int *>(p); p += sn::align_up((size_t)b * n * 16, 256);
   ws.max_inc = reinterpret_cast<float *>(p); p += arr;
   ws.max_idx = reinterpret_cast<int *>(p); p += arr;
   ws.head = reinterpret_cast<int *>(p); p += arr;
@@ -2277,8 +2285,8 @@ extern "C" long long sn_emd_prof_exec(double *total_ms, int reset) {
 
 extern "C" size_t sn_emd_workspace_bytes(int b, int n) {
   if (b < 1 || n < 1) return 0;
-  return 14 * sn::align_up((size_t)b * n * 4, 256) + 3 * sn::align_up((size_t)b * n * 8, 256) +
-         2 * sn::align_up((size_t)b * kRankBins * 4, 256) + 2 * sn::align_up((size_t)b * n * 16, 256) +
+  return 14 * sn::align_up((size_t)b * n * 4, 256) + 2 * sn::align_up((size_t)b * n * 8, 256) +
+         2 * sn::align_up((size_t)b * kRankBins * 4, 256) + 3 * sn::align_up((size_t)b * n * 16, 256) +
          2 * (size_t)b * kSortCells * 4 + 2 * sn::align_up((size_t)b * 24, 256) +
          sn::align_up((size_t)b * (n / 16) * 32, 256) + sn::align_up((size_t)b * 4, 256) + kCtlBytes;
 }

@@ -44,9 +44,10 @@ def test_argument_validation_without_gpu():
     assert b"power of two" in lib.sn_last_error()
     assert lib.sn_mds(one, 1, 10, 20, one, one, null, ctypes.c_size_t(0), null) == -22
     ctl = 4 * (32 + 32 * 1024) + 8 * (16 + 64 * 64)   # persistent auction: barrier counters + diag words
-    # 14 word arrays + 3 arrays of 8-byte entries (bid records, {index, rank} lists, {price, index} stream) + ...
-    assert lib.sn_emd_workspace_bytes(32, 16384) == (14 * 32 * 16384 * 4 + 3 * 32 * 16384 * 8 + 2 * 32 * 256 * 4
-                                                      + 2 * 32 * 16384 * 16 + 2 * 32 * 4096 * 4 + 2 * 768
+    # 14 word arrays + 2 arrays of 8-byte entries ({index, rank} lists, {price, index} stream) + 3 of 16-byte entries
+    # (bid records {increment, next, index, -}, target records, matrix-core operands) + ...
+    assert lib.sn_emd_workspace_bytes(32, 16384) == (14 * 32 * 16384 * 4 + 2 * 32 * 16384 * 8 + 2 * 32 * 256 * 4
+                                                      + 3 * 32 * 16384 * 16 + 2 * 32 * 4096 * 4 + 2 * 768
                                                       + 32 * 1024 * 32 + 256 + ctl)   # ... + the far-bidder counters
 
 
