@@ -33,6 +33,16 @@
 //     (atomic exchange on the target's head word); after ONE team barrier the list's head walks it, applies the
 //     reference's +-1e-6 window and its highest-bidder-index rule, awards the target and re-flags the losers.
 //     Two team barriers per iteration instead of three, no separate GetMax pass.
+//   * What the auction costs depends on the DATA (round 5; tools/emd_regimes.py, bench.py `emd_regimes`): uniform cubes
+//     are its easiest input.  A prediction that lies OFF the targets' surface (counted by the seed kernel) bids with
+//     the per-bidder scan from the first iteration on, its workgroups own a transposed comb of rank bins instead of a
+//     contiguous range (the cost per bidder is what varies there) and the scan re-tightens its reach between lists;
+//     a CONTESTED auction (hundreds of bidders per target: the refine stages of an untrained generator) is noticed by
+//     the award phase's walkers, and from the next iteration on a bidder that finds its target's running maximum
+//     already above its own increment does not enter the target's list at all.  All of it exact: which workgroup
+//     serves a bidder, in which order, and whether a certain loser is linked never enter a result.
+//   * A raised flag IS the bidder's index (+ 1) and the index travels in the bid record: neither the compaction nor
+//     the award phase looks anything up in the permutation.
 #include <atomic>
 #include <chrono>
 #include <cstdlib>

@@ -1083,21 +1083,38 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   float bg = 0.f;
+  // llrint(x * scale) through the 1.5 * 2^52 trick: scale is a power of two (the product is exact) and every
+  // |term| < 2^44, so rn(x * scale + 1.5 * 2^52) carries rint(x * scale) in its low mantissa bits -- the same
+  // integer as llrint under round-to-nearest-even, in 4 instructions instead of the library's 8 fp64 ones per term
+  auto fixed = [&](float x) {
+    const double m = 6755399441055744.0;  // 1.5 * 2^52
+    return (unsigned long long)(__double_as_longlong(__builtin_fma((double)x, scale, m)) - __double_as_longlong(m));
+  };
   for (int k = 0; k < nradii; ++k) {
     const float gk = valid ? out_grad[(size_t)k * orstride + oe] : 0.f;
     const int pid = valid ? out_ids[(size_t)k * orstride + oe] : -1;
-    if (pid < 0) {
-      bg += gk;
-      continue;
+    const bool has = pid >= 0;
+    if (!has) bg += gk;
+    unsigned long long t0 = 0ull, t1 = 0ull, t2 = 0ull;
+    if (has) {
+      // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
+      // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
+      const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+      const float dx = x - px, dy = y - py;
+      const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
+      const float fv = feat[(size_t)pid * channels + c];
+      const float cf = gk * weight32(u);
+      const float kk = gk * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
+      t0 = fixed(cf);
+      t1 = fixed(kk * dy);
+      t2 = fixed(kk * dx);
     }
-    // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
-    // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
-    const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
-    const float dx = x - px, dy = y - py;
-    const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
-    const float fv = feat[(size_t)pid * channels + c];
-    const float cf = gk * weight32(u);
-    const float kk = gk * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
+    bool live = has;
+    // (Round 5 merged the terms of neighbouring pixels with the same winner -- lane ^ 1, then lane ^ 8 -- before the
+    // table's atomics, to take the same-address LDS atomics down (SQ_LDS_BANK_CONFLICT 11.7 cycles per LDS
+    // instruction): exact, and no faster -- 491.9 -> 494.1 us at 8 views x 32 clouds.  The kernel's time is the ~45
+    // GLOBAL 8-byte atomics per tile (11.8 M per launch), not the table; removed.)
+    if (!live) continue;
     unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
     bool found = false;
     for (int probe = 0; probe < kAccProbes; ++probe) {
@@ -1108,16 +1125,6 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
       }
       slot = (slot + 1) & (kAccSlots - 1);
     }
-    // llrint(x * scale) through the 1.5 * 2^52 trick: scale is a power of two (the product is exact) and every
-    // |term| < 2^44, so rn(x * scale + 1.5 * 2^52) carries rint(x * scale) in its low mantissa bits -- the same
-    // integer as llrint under round-to-nearest-even, in 4 instructions instead of the library's 8 fp64 ones per term
-    auto fixed = [&](float x) {
-      const double m = 6755399441055744.0;  // 1.5 * 2^52
-      return (unsigned long long)(__double_as_longlong(__builtin_fma((double)x, scale, m)) - __double_as_longlong(m));
-    };
-    const unsigned long long t0 = fixed(cf);
-    const unsigned long long t1 = fixed(kk * dy);
-    const unsigned long long t2 = fixed(kk * dx);
     if (found) {
       atomicAdd(&vals[wave][slot][0], t0);
       atomicAdd(&vals[wave][slot][1], t1);
