@@ -1140,7 +1140,11 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     int team_g = 1, team_slots = 0;
     // a cloud goes to a team when its cut ball's squared radius exceeds this fraction of the squared diagonal of
     // its bounding box (SN_MDS_RATIO; measured cross-over)
-    static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.12f; return v > 0.f ? v : 0.12f; }();
+    // (0.12 in rounds 3-4, from uniform cubes at chosen mean MST lengths.  The first sampler call of an UNTRAINED generator
+    // -- the decoder's cube + the partial input, ratio between 0.06 and 0.12 -- ran 44 ms in the one-workgroup kernel where a
+    // team takes 27: config 4 at random init 110.7 -> 93.1 ms per step with 0.06; a trained generator's surface clouds stay
+    // far below either value, and 0.03 starts to send them to teams: 72.7 -> 77.7 ms.  profiles/r05_e_mds_team_ratio.txt)
+    static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.06f; return v > 0.f ? v : 0.06f; }();
     {
       int dev = 0, cus = 0;
       SN_HIP(hipGetDevice(&dev));

@@ -39,6 +39,7 @@ echo "== strong share"; timeout 600 python tools/strong_share.py 2>&1 | grep -v 
 echo "== host overhead"; (HO_B=4 timeout 300 python tools/host_overhead.py; HO_B=32 timeout 300 python tools/host_overhead.py) 2>&1 | grep -v amdgpu | tee $O/host_overhead.txt
 echo "== render kernels"; (python tools/render_probe.py; KTOP=12 tools/kstats.sh tools/render_probe.py) 2>&1 | grep -v "amdgpu\|^E2026" | tee $O/render_kernels.txt | tail -12
 echo "== sampler on surface clouds"; timeout 600 python tools/mds_surface.py --parity 2>&1 | grep "mds surface" | tee $O/mds_surface.txt
+echo "== sampler: dense / intermediate / surface regimes per batch (teams from cut^2 > 0.06 diag^2 on)"; timeout 600 python tools/mds_ab.py 2>&1 | grep "^mds" | tee $O/mds_regimes.txt
 echo "== network steps: steady-state kernel tables"
 cd /tmp
 for cfg in config4 config5; do
@@ -51,6 +52,6 @@ for cfg in config4 config5; do
   done
 done
 cd $R
-echo "== launcher"; BENCH_DEBUG_SHARED_GPU=1 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-roofline 2>/dev/null | grep '^{' > $O/bench_gpus2_shared_gpu.json; python -c "
-import json; d=json.load(open('$O/bench_gpus2_shared_gpu.json')); print({k: d[k] for k in ('n_gpus','scaling','ms_per_step')}, d['rccl_ranks']['backend'], d['other_scaling']['scaling'], d['other_scaling']['ms_per_step'])"
+echo "== launcher"; BENCH_DEBUG_SHARED_GPU=1 timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-roofline 2>/dev/null > $O/bench_gpus2.out; python -c "
+import json; t=open('$O/bench_gpus2.out').read(); t=t[t.index('{\"metric\"'):]; d=json.loads(t[:t.rindex('}')+1]); json.dump(d, open('$O/bench_gpus2_shared_gpu.json','w')); print({k: d[k] for k in ('n_gpus','scaling','ms_per_step')}, d['rccl_ranks']['backend'], d['other_scaling']['scaling'], d['other_scaling']['ms_per_step'])"
 echo done > $O/done.txt
