@@ -1141,10 +1141,12 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     // a cloud goes to a team when its cut ball's squared radius exceeds this fraction of the squared diagonal of
     // its bounding box (SN_MDS_RATIO; measured cross-over)
     // (0.12 in rounds 3-4, from uniform cubes at chosen mean MST lengths.  The first sampler call of an UNTRAINED generator
-    // -- the decoder's cube + the partial input, ratio between 0.06 and 0.12 -- ran 44 ms in the one-workgroup kernel where a
-    // team takes 27: config 4 at random init 110.7 -> 93.1 ms per step with 0.06; a trained generator's surface clouds stay
-    // far below either value, and 0.03 starts to send them to teams: 72.7 -> 77.7 ms.  profiles/r05_e_mds_team_ratio.txt)
-    static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.06f; return v > 0.f ? v : 0.06f; }();
+    // -- the decoder's cube + the partial input, ratio between 0.09 and 0.12 -- ran 44 ms in the one-workgroup kernel where a
+    // team takes 27: config 4 at random init 110.7 -> 93.9 ms per step, config 5 179 -> 134 with 0.075; 0.09 still leaves some
+    // of config 5's clouds behind (171); a surface cloud at mean MST length 0.02 sits between 0.06 and 0.075 and is better
+    // off on one workgroup (23.5 ms against 26-28 on a team), a trained generator's clouds are far below either.
+    // profiles/r05_g_mds_team_ratio.txt)
+    static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.075f; return v > 0.f ? v : 0.075f; }();
     {
       int dev = 0, cus = 0;
       SN_HIP(hipGetDevice(&dev));

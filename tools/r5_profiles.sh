@@ -39,7 +39,7 @@ echo "== strong share"; timeout 600 python tools/strong_share.py 2>&1 | grep -v 
 echo "== host overhead"; (HO_B=4 timeout 300 python tools/host_overhead.py; HO_B=32 timeout 300 python tools/host_overhead.py) 2>&1 | grep -v amdgpu | tee $O/host_overhead.txt
 echo "== render kernels"; (python tools/render_probe.py; KTOP=12 tools/kstats.sh tools/render_probe.py) 2>&1 | grep -v "amdgpu\|^E2026" | tee $O/render_kernels.txt | tail -12
 echo "== sampler on surface clouds"; timeout 600 python tools/mds_surface.py --parity 2>&1 | grep "mds surface" | tee $O/mds_surface.txt
-echo "== sampler: dense / intermediate / surface regimes per batch (teams from cut^2 > 0.06 diag^2 on)"; timeout 600 python tools/mds_ab.py 2>&1 | grep "^mds" | tee $O/mds_regimes.txt
+echo "== sampler: dense / intermediate / surface regimes per batch (teams from cut^2 > 0.075 diag^2 on)"; timeout 600 python tools/mds_ab.py 2>&1 | grep "^mds" | tee $O/mds_regimes.txt
 echo "== network steps: steady-state kernel tables"
 cd /tmp
 for cfg in config4 config5; do
