@@ -194,12 +194,29 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned v) {
   return v;
 }
 
-// wave-uniform minimum over the 64 lanes
+// wave-uniform minimum over the 64 lanes.  The DPP modifier sits ON the v_min (as in the renderer's tile minimum,
+// p2i.hip): four steps inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them, lane 63 ends up with the
+// minimum: six vector instructions + one v_readlane, where mov_dpp + min pairs, four v_readlane and three scalar minima
+// took fifteen (SN_WAVE_MIN_PLAIN restores them for A/B).  "s_nop 1": a DPP operand written by the previous vector
+// instruction needs two wait states, which nobody inserts inside inline assembly.
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-  v = row_min_u32(v);
+#ifdef SN_WAVE_MIN_PLAIN
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
+  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));  // row_mirror
   const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
   const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
   return umin32(umin32(a, b), umin32(c, d));
+#else
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+#endif
 }
 
 // sn_expf (include/sn_expf.h) for arguments x <= 0 (or NaN): the same correctly rounded
@@ -922,7 +939,10 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     const unsigned minv = row_min_u32(v16);
     const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
     const unsigned minl = row_min_u32(lw);
-    // this workgroup's candidate: (minv, minl); "nothing below 1e9" travels as (>= kBig, all ones)
+    // this workgroup's candidate: (minv, minl); "nothing below 1e9" travels as (>= kBig, all ones).
+    // (Round 5 let the candidate's COORDINATES ride with it -- four stamped 64-bit words per member and round instead of
+    // one, so that nobody reads the pick's coordinates from xyz afterwards: index-exact, and slower, 30.8 -> 32.1 ms at 32
+    // clouds, 27.2 -> 28.9 at 4: the uniform load of constant data that it saves is cheaper than four words per poll.)
     if (wave == 0) {  // ONE wave per workgroup talks to the others (sixteen pollers per workgroup on the same lines
                       // slowed every store down); the rest of the workgroup waits at the barrier below
       const unsigned my_val = (unsigned)__builtin_amdgcn_readfirstlane((int)minv);
