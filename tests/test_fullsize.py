@@ -337,8 +337,13 @@ off = L.lib().sn_emd_diag_offset(b, n)
 local_teams = int(ws[off:off + 8 * 16].view(torch.int64)[12])
 print("RESULT", int(np.array_equal(a.cpu().numpy(), a0)), int(np.array_equal(d.cpu().numpy(), d0)), local_teams)
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for diag, want_local in (("4", 0), ("1", 32)):
+    # (third run: mixed teams with round 5's contested / off-surface paths forced on -- the outbid marks, the re-flagging
+    # in the award phase, the `cont` stamps in the team's barrier block and the transposed split all through agent-scope
+    # stores)
+    for diag, want_local, forced in (("4", 0, False), ("1", 32, False), ("4", 0, True)):
         env = dict(os.environ, SN_EMD_DIAG=diag)
+        if forced:
+            env.update(SN_EMD_SKIP="2", SN_EMD_SPREAD="2")
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")]
         assert line, out.stderr[-2000:]
@@ -503,8 +508,19 @@ def test_emd_self_test_passes_and_safe_mode_is_bit_exact(dev):
         db, ab = oracle.emd_forward(xb, yb, 0.005, 20, mt=True)
         (d, a), _ = _emd_raw(xb, yb, 0.005, 20, dev)
         assert np.array_equal(a.cpu().numpy(), ab) and np.array_equal(d.cpu().numpy(), db)
+        # the fenced path with round 5's contested / off-surface paths forced on (a contested cloud: lists of hundreds)
+        os.environ["SN_EMD_SKIP"], os.environ["SN_EMD_SPREAD"] = "2", "2"
+        gc = torch.Generator().manual_seed(6)
+        yc = torch.randn(9, 2048, 3, generator=gc)
+        yc = (0.5 * yc / yc.norm(dim=2, keepdim=True)).contiguous()
+        xc = (yc + 2 * torch.rand(9, 2048, 3, generator=gc) - 1).contiguous()
+        dc, ac = oracle.emd_forward(xc.numpy(), yc.numpy(), 0.005, 15, mt=True)
+        (d, a), _ = _emd_raw(xc.numpy(), yc.numpy(), 0.005, 15, dev)
+        assert np.array_equal(a.cpu().numpy(), ac) and np.array_equal(d.cpu().numpy(), dc)
     finally:
         del os.environ["SN_EMD_SAFE"]
+        os.environ.pop("SN_EMD_SKIP", None)
+        os.environ.pop("SN_EMD_SPREAD", None)
 
 
 @pytest.mark.gpu
