@@ -99,7 +99,9 @@ int sn_chamfer_backward(const float *xyz1, const float *xyz2,
  * cuda/chamfer_distance/chamfer_distance.py:31-32,53-54; BASELINE config 1).  All pointers are HOST pointers, the
  * calls are synchronous.  Same values as the device entry points and as the reference's CPU code bit for bit: fp32
  * distances (dx*dx + dy*dy) + dz*dz without contraction, lowest index among equal minima, the backward's additions in
- * the reference's order.  threads: worker threads (0 = one per hardware thread; SN_HOST_THREADS overrides).
+ * the reference's order.  threads: worker threads; an explicit value > 0 is taken as given.  0 = the default: one per
+ * hardware thread, or SN_HOST_THREADS when set -- the default (either form) is then reduced so that every thread
+ * has at least four work items (clouds x query blocks).  Never more than 256, never more than there are items.
  * The library's own host code, not a fallback: device tensors never take this path. */
 int sn_chamfer_forward_host(const float *xyz1, const float *xyz2, int b, int n,
                             int m, float *dist1, int *idx1, float *dist2,

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 
 #include "../../include/sparenet_hip.h"
 
@@ -112,6 +113,23 @@ inline bool capture_allowed() {
 #define SN_REFUSE_CAPTURE(stream, what)                                                                     \
   SN_REQUIRE(!sn::capturing(stream) || sn::capture_allowed(), what ": the stream is being captured into a HIP graph; this op does not " \
                                            "replay correctly from a graph (see common.hpp) -- launch it eagerly")
+
+// Tuning / test knobs from the environment are read ONCE per process, at their first use -- unless
+// SN_KNOBS_PER_CALL=1 (tests/conftest.py sets it before the library is loaded: the tests switch knobs inside one
+// process).  SN_KNOB("NAME") = the value (a private copy) or nullptr.
+inline bool knobs_per_call() {
+  static const bool v = [] { const char *e = getenv("SN_KNOBS_PER_CALL"); return e && e[0] == '1'; }();
+  return v;
+}
+#define SN_KNOB(name)                                                                   \
+  ([]() -> const char * {                                                               \
+    if (sn::knobs_per_call()) return getenv(name);                                      \
+    static const std::string v = [] {                                                   \
+      const char *e = getenv(name);                                                     \
+      return e ? std::string(e) : std::string("\x01");                                  \
+    }();                                                                                \
+    return v[0] == '\x01' ? nullptr : v.c_str();                                        \
+  }())
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }

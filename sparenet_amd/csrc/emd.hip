@@ -425,7 +425,10 @@ __global__ __launch_bounds__(kThreads) void emd_seed_kernel(int B, int n,
     // none, scattered +-0.3 around the surface: 58 %, the refine stages of an untrained generator: 85 %.)  Counted on
     // every eighth wave, scaled by 8: one atomic per wave on the cloud's counter took 58 us at 32 clouds (256
     // serialised atomics per word), an eighth of them is an estimate that is good enough for a 25 % threshold.
-    if (((e >> 6) & 7) == 0) {  // wave-uniform (n % 1024 == 0: a wave never straddles two clouds)
+    // (which eighth: ONE wave of every eight consecutive ones, at an offset that rotates from group to group --
+    // exactly n / 512 samples per cloud, spread over the Hilbert curve instead of the first wave of every group)
+    const unsigned wv = (unsigned)((e - bb * n) >> 6);
+    if (((wv * 5u) & 7u) == ((wv >> 3) & 7u)) {  // wave-uniform (n % 1024 == 0: a wave never straddles two clouds)
       const float *bx = ws.sbbox + (bb * (n >> 4) + ((lo + 8) >> 4)) * 8;
       const float ex = bx[3] - bx[0], ey = bx[4] - bx[1], ez = bx[5] - bx[2];
       const unsigned long long farm = __ballot(16.f * s1 > (ex * ex + ey * ey) + ez * ez);
@@ -647,9 +650,12 @@ struct AuctionCtl {  // zeroed by a memset node before every launch
 // every chunk; the iteration of the scattered probe got 70 % longer while the thieves were busy
 // (profiles/r05_a_emd_handoff_not_kept.txt).  What balances the team instead is WHICH ranks a workgroup owns: see
 // the split at the top of an iteration.)
-// The words live in the team's 128-byte barrier block (AuctionCtl::bar + 32 team: word 0 the counter, word 1 the
-// mixed-XCD flag, words 2-3 cont[2]): zeroed with it, no second memset node.
-constexpr int kNoteWord = 2;
+// The words live in a 128-byte block of their own per team, BEHIND the teams' barrier blocks (AuctionCtl::bar + 32
+// (teams + team): words 0-1 = cont[2]) and are zeroed by the same memset node: the barrier block's line is the one
+// thread 0 of every workgroup of the team polls, a store to it bounces that line between the pollers.  Stamps are
+// full 32-bit words (cloud_seq (iters + 1) + it + 1 cannot wrap: b <= 512 clouds, the stamp of an ALIASED word would
+// only force the contested mode, which is exact too).
+constexpr int kNoteWord = 0;
 
 struct TeamGeom {
   int G;       // workgroups per team (power of two)
@@ -1581,7 +1587,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
   int *flags = a.ws.flags;
   int *llist_all = a.ws.list[0];
   BidOut bo = {a.ws.bid, a.ws.bid2, a.ws.rec, a.ws.max_inc, a.ws.head, loc, 0};
-  unsigned *const note = a.ctl->bar + (size_t)team * 32 + kNoteWord;  // cont[2] of this team (see kNoteWord)
+  unsigned *const note = a.ctl->bar + (size_t)(a.tg.teams + team) * 32 + kNoteWord;  // cont[2] of this team (see kNoteWord)
   int cloud_seq = 0;
   if (a.diag && m == 0 && tid == 0 && loc) atomicAdd(reinterpret_cast<unsigned long long *>(a.dwords) + 12, 1ull);  // teams on one XCD
 
@@ -1669,7 +1675,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
       // TRANSPOSED order, position p = bin (p mod K) G + p div K, K = 256 / G: a workgroup's run of positions is a
       // comb of bins spread evenly over the whole curve, every workgroup a sample of every region.  No protocol, no
       // atomics; the bidders' order inside a list never enters a result.
-      const unsigned stamp = (stamp0 + (unsigned)it + 1u) & 0xffffffu;
+      const unsigned stamp = stamp0 + (unsigned)it + 1u;
       const bool last = it == a.iters - 1;
       if (wave == 0) {  // lane l holds the bins (positions) 4 l .. 4 l + 3
         const int2 lo2 = ldc2(a.ws.bins[cur] + b * kRankBins + 4 * lane);
@@ -1993,7 +1999,7 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
           // uniform clouds: 20-30 % in the early iterations -- there the second round trip per bid costs 1.6 us per
           // iteration and buys nothing
           if (L.s_long || (L.s_skipped >= 16 && 2 * L.s_skipped >= Um))
-            stc(loc, reinterpret_cast<int *>(&note[cur ^ 1]), (int)((stamp + 1u) & 0xffffffu));
+            stc(loc, reinterpret_cast<int *>(&note[cur ^ 1]), (int)(stamp + 1u));
           L.s_long = 0;
           L.s_skipped = 0;
         }
@@ -2054,7 +2060,7 @@ __global__ __launch_bounds__(kThreads) void emd_bwd_kernel(
 }
 
 constexpr size_t kDiagWords = 16 + 64 * 64;                        // int64 phase timers (SN_EMD_DIAG)
-constexpr size_t kCtlWords = 32 + 32 * 1024;                        // ticket, abort, up to 1024 team counters
+constexpr size_t kCtlWords = 32 + 2 * 32 * 1024;                    // ticket, abort, up to 1024 team counters + 1024 note blocks
 constexpr size_t kCtlBytes = 4 * kCtlWords + 8 * kDiagWords;
 
 EmdWs carve(void *workspace, int b, int n) {
@@ -2313,7 +2319,7 @@ extern "C" int sn_emd_mode(void) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -1;
   std::lock_guard<std::mutex> lk(g_dev_mu);
-  const char *e = getenv("SN_EMD_SAFE");
+  const char *e = SN_KNOB("SN_EMD_SAFE");
   if (e && e[0] == '1') return 2;
   if (g_dev[dev].verified == 2) {
     sn::fail(0, "%s", g_dev[dev].why);
@@ -2359,7 +2365,7 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
   if (const int rc = sn::check_sticky(dev, "sn_emd_forward")) return rc;
   SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
   SN_REQUIRE(cus >= 1 && cus <= 1024, "sn_emd_forward: unexpected compute-unit count %d", cus);
-  const char *safe_env = getenv("SN_EMD_SAFE");   // read per call: tests switch it inside one process
+  const char *safe_env = SN_KNOB("SN_EMD_SAFE");   // once per process; per call under SN_KNOBS_PER_CALL=1 (tests)
   int safe = safe_env && safe_env[0] == '1';
   unsigned *sticky = sn::sticky_device_word(dev);
   {
@@ -2409,8 +2415,8 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     static const int diag = [] { const char *e = getenv("SN_EMD_DIAG"); return e ? atoi(e) : 0; }();
     static const int gmax = [] { const char *e = getenv("SN_EMD_G"); const int v = e ? atoi(e) : 64; return v >= 1 ? v : 64; }();
     static const int legacy = [] { const char *e = getenv("SN_EMD_GEOM"); return e && e[0] == '1' ? 1 : 0; }();
-    {  // read per call: the tests compare the two bid paths inside one process
-      const char *e = getenv("SN_EMD_SCAN");
+    {  // once per process; per call under SN_KNOBS_PER_CALL=1 (the tests compare the two bid paths inside one process)
+      const char *e = SN_KNOB("SN_EMD_SCAN");
       const int v = e ? atoi(e) : SN_EMD_SCAN_MAX;
       args.scan_max = v < 0 ? 0 : v;
     }
@@ -2421,15 +2427,15 @@ extern "C" int sn_emd_forward(const float *xyz1, const float *xyz2, int b, int n
     static const unsigned spin_env = [] { const char *e = getenv("SN_EMD_SPIN_LIMIT"); return e ? (unsigned)atol(e) : 0u; }();
     args.spin_limit = (diag & 8) ? (1u << 15) : (spin_env ? spin_env : kSpinLimit);   // SN_EMD_SPIN_LIMIT: debugging aid
     args.dwords = reinterpret_cast<long long *>(static_cast<char *>(ws.ctl) + 4 * kCtlWords);
-    {  // read per call: the tests compare the settings inside one process
-      const char *e = getenv("SN_EMD_SKIP");
+    {  // once per process; per call under SN_KNOBS_PER_CALL=1 (the tests compare the settings inside one process)
+      const char *e = SN_KNOB("SN_EMD_SKIP");
       args.skip_mode = e ? atoi(e) : 1;
-      e = getenv("SN_EMD_SPREAD");
+      e = SN_KNOB("SN_EMD_SPREAD");
       args.spread_mode = e ? atoi(e) : 1;
     }
     SN_REQUIRE(args.tg.teams <= 1024, "sn_emd_forward: too many teams (%d)", args.tg.teams);
     if (diag) SN_HIP(hipMemsetAsync(args.dwords, 0, 8 * kDiagWords, s));
-    SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 32 * (size_t)args.tg.teams), s));
+    SN_HIP(hipMemsetAsync(ws.ctl, 0, 4 * (32 + 2 * 32 * (size_t)args.tg.teams), s));   // barrier blocks + note blocks
     {
       // 140 KB of dynamic LDS: above the 64 KB a launch may ask for unannounced.  Every call: the attribute belongs
       // to the CURRENT device (several devices per process), and a failure must be reported by the call that meets it.

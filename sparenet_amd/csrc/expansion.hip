@@ -17,6 +17,7 @@
 // centric: the lane that owns child c decides the edge (c, parent[c]) from a
 // snapshot of both endpoint degrees.
 #include "common.hpp"
+#include "wave_dpp.hpp"
 
 namespace {
 
@@ -26,30 +27,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned umin32(unsigned a, unsigned b) { return a < b ? a : b; }
 
-// wave-uniform minimum over the 64 lanes.  The DPP modifier sits ON the v_min (as in the renderer's tile minimum,
-// p2i.hip): four steps inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them, lane 63 ends up with the
-// minimum: six vector instructions + one v_readlane, where mov_dpp + min pairs, four v_readlane and three scalar minima
-// took fifteen (SN_WAVE_MIN_PLAIN restores them for A/B).  "s_nop 1": a DPP operand written by the previous vector
-// instruction needs two wait states, which nobody inserts inside inline assembly.
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#ifdef SN_WAVE_MIN_PLAIN
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));  // row_mirror
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  return umin32(umin32(a, b), umin32(c, d));
-#else
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-#endif
-}
+// wave-uniform minimum over the 64 lanes: wave_dpp.hpp (one definition for the sampler, the expansion penalty and
+// the renderer)
+using sn::wave_min_u32;
 
 // A vertex that is in the tree (or a padding slot) carries this key: as a SIGNED int it is below every
 // squared length, so the relaxation test never fires; as an UNSIGNED int it is above every squared

@@ -22,37 +22,12 @@
 
 #include "cloud_sort.hpp"
 #include "common.hpp"
+#include "wave_dpp.hpp"
 #include "../../include/sn_expf.h"
 
-// Round 5's two attempts at the surface regime's round (both index-exact against the oracle on every test and on
-// whole 19384 -> 16384 surface clouds, both SLOWER, both compiled out; profiles/r05_c_mds_rounds_not_kept.txt):
-//   SN_MDS_PICKS = 2 .. 4: several picks per round (3.3 per round with at most 4 on surface clouds) -- 19.0 ms against
-//     18.4 at 4, 24.2 at 2: the round is a chain of DEPENDENT steps per wave and the accepted picks' updates still
-//     run one after the other inside it; what the round saves (one hand-off + barrier per extra pick) it spends on
-//     ordering the sixteen candidates and testing the pairs;
-//   SN_MDS_LAZY = 1: slot summaries only when a slot's stale lower bound surfaces as the wave's minimum -- 25.6 ms
-//     against 18.3: the slots near a pick are the low-density ones, their bounds surface at once, and the refresh
-//     loop's own reductions come on top.
-// picks per round of the one-workgroup sampler in the surface regime (1: round 4's loop; see mds_clustered_kernel)
-#ifndef SN_MDS_PICKS
-#define SN_MDS_PICKS 1
-#endif
-// lazy slot summaries in the surface regime's single-pick loop (see mds_clustered_kernel)
-#ifndef SN_MDS_LAZY
-#define SN_MDS_LAZY 0
-#endif
-
-#ifdef SN_MDS_STATS   // experiment builds: how many picks the multi-pick rounds of cloud 0 took (histogram by picks per round)
-__device__ unsigned long long g_mds_rounds[8];
-extern "C" int sn_mds_debug_rounds(unsigned long long *out8, int reset) {
-  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mds_rounds), 64) != hipSuccess) return -1;
-  if (reset) {
-    unsigned long long z[8] = {0};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mds_rounds), z, 64) != hipSuccess) return -1;
-  }
-  return 0;
-}
-#endif
+// Round 5's two attempts at the surface regime's round -- several picks per round (exact, 3.3 picks per round, 19.0 ms
+// against 18.4) and lazy slot summaries (25.6 ms against 18.3) -- were index-exact and slower; they live in the git
+// history (commit 255d4b0 and before) and in profiles/r05_c_mds_rounds_not_kept.txt, not in this file.
 
 namespace {
 
@@ -194,30 +169,9 @@ __device__ __forceinline__ unsigned row_min_u32(unsigned v) {
   return v;
 }
 
-// wave-uniform minimum over the 64 lanes.  The DPP modifier sits ON the v_min (as in the renderer's tile minimum,
-// p2i.hip): four steps inside the rows of 16 lanes, row_bcast:15 / row_bcast:31 across them, lane 63 ends up with the
-// minimum: six vector instructions + one v_readlane, where mov_dpp + min pairs, four v_readlane and three scalar minima
-// took fifteen (SN_WAVE_MIN_PLAIN restores them for A/B).  "s_nop 1": a DPP operand written by the previous vector
-// instruction needs two wait states, which nobody inserts inside inline assembly.
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-#ifdef SN_WAVE_MIN_PLAIN
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true));   // quad_perm 1,0,3,2
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true));   // quad_perm 2,3,0,1
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true));  // row_half_mirror
-  v = umin32(v, (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true));  // row_mirror
-  const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
-  const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-  return umin32(umin32(a, b), umin32(c, d));
-#else
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
-  asm volatile("s_nop 1\n\tv_min_u32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-#endif
-}
+// wave-uniform minimum over the 64 lanes: wave_dpp.hpp (one definition for the sampler, the expansion penalty and
+// the renderer)
+using sn::wave_min_u32;
 
 // sn_expf (include/sn_expf.h) for arguments x <= 0 (or NaN): the same correctly rounded
 // operations in the same order, so it returns the bits sn_expf returns.  The x > 88 clamp is
@@ -327,8 +281,6 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
   // run (every region already holds picks) this is a ~3x smaller ball than (1).
   const float far2 = cut2 * 1.001f;
   unsigned sval = 0xffffffffu, slow = 0xffffffffu;
-  unsigned ssec = 0xffffffffu;  // the slot's SECOND smallest density (equal densities count): see the multi-pick rounds
-  (void)ssec;
   float sx = 0.f, reach2 = -1.f;
   int sown = 0;
   auto summarize = [&](int i, unsigned tv, unsigned lw, float x) {  // i: static slot index
@@ -339,11 +291,6 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
       eq = __ballot(cand == wave_min_u32(cand));
     }
     const int own = (int)__builtin_ctzll(eq);
-#if SN_MDS_PICKS > 1
-    const unsigned sm2 = wave_min_u32(lane == own ? 0xffffffffu : tv);
-#else
-    const unsigned sm2 = 0xffffffffu;
-#endif
     const unsigned o_low = (unsigned)__builtin_amdgcn_readlane((int)lw, own);
     const float o_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), own));
     const float vmin = __uint_as_float(sm);
@@ -359,7 +306,6 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
       slow = o_low;
       sx = o_x;
       sown = own;
-      ssec = sm2;
       reach2 = (blx <= bhx) ? r2 : -1.f;  // empty slot: never near
     }
   };
@@ -469,186 +415,12 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
     }
     return;
   }
-#if SN_MDS_PICKS > 1
-  // ---------------------------------------------------------------------------------------------------------
-  // Several picks per round (round 5).  The sampler is m - 1 DEPENDENT rounds at the latency floor of one
-  // compute unit (update -> arg-min in the wave -> LDS -> barrier -> arg-min over the waves: 1.1 us), so the lever
-  // that is left is fewer rounds.  After pick 1 = the smallest key, the next pick of the reference's sequential
-  // loop is the smallest key AFTER pick 1's update; densities only grow, so that is simply the next smallest OLD
-  // key -- provided that point itself is not changed by pick 1 (it lies outside the cut ball, or the increment is
-  // absorbed by the rounding of its density: decided by evaluating the update for exactly that point) and provided
-  // nothing that ranks below it can have been overlooked.  Every wave hands over its smallest key W (with the
-  // point's coordinates) and the second smallest density S among its points; with the waves ordered by W,
-  //   pick k = the point of wave w_k   iff   for every earlier pick j < k of the round:
-  //            S[w_j] > density(pick k)      (wave w_j holds nothing else below pick k; equal counts as "may")
-  //            and pick j's update leaves pick k's density unchanged (bit for bit),
-  // and every point of every other wave has an old key above W[w_k] by the order itself.  The first pick that fails
-  // ends the round; the accepted ones are applied IN ORDER (each density takes its increments in pick order: the
-  // per-round rounding of (float)((double)temp + w exp) is replayed exactly), the touched slots are summarised once.
-  // Replayed in numpy on a 19384-point surface cloud (mml 0.010): 3.3 picks per round with at most 4, 4.3 with at
-  // most 8; the dense regime (the cut ball covers the cloud) never gets past one and keeps its own loop above.
-  // The index sequence is the reference's by construction; tests/test_mds.py compares it with the oracle's.
-  // ---------------------------------------------------------------------------------------------------------
-  {
-    constexpr int K = SN_MDS_PICKS;  // at most this many picks per round (2 .. 4)
-    __shared__ unsigned wave_sec[2][16];
-    int j = 1, buf = 0;
-    // the picks decided at the end of the previous turn, applied at the top of this one (ONE copy of the update and
-    // of the summaries in the kernel's code): first point 0, the first sample (idx[0] = 0)
-    int npick = 1;
-    bool from_table = false;  // false: the pick is point 0
-    int sel[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) sel[k] = 0;
-    float4 pk = make_float4(0.f, 0.f, 0.f, 0.f);
-    unsigned lw16 = 0;
-    for (;;) {
-      unsigned touched = 0;
-      for (int r = 0; r < npick; ++r) {  // uniform
-        if (from_table) {
-          const int sl = r == 0 ? sel[0] : (r == 1 ? sel[1 < K ? 1 : 0] : (r == 2 ? sel[2 < K ? 2 : 0] : sel[K - 1]));
-          x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.x), sl));
-          y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.y), sl));
-          z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk.z), sl));
-          last_low = (unsigned)__builtin_amdgcn_readlane((int)lw16, sl);
-        } else {
-          x1 = x0, y1 = y0, z1 = z0;
-          last_low = 0;
-        }
-        const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
-        const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
-        const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
-        const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < reach2);
-        touched |= mask;
-#pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-          if ((mask >> i) & 1u) {  // wave-uniform
-            const float v = (low[i] == last_low) ? 1e9f : tmp[i];
-            const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
-            const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
-            const float d = (dx * dx + dy * dy) + dz * dz;
-            const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
-            // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
-            tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < PPT; ++i)
-        if ((touched >> i) & 1u) summarize(i, __float_as_uint(tmp[i]), low[i], px[i]);
-      if (j >= m) break;
-
-      // this wave's smallest key (as in the single-pick loop) and the second smallest density among its points
-      const unsigned wm = wave_min_u32(sval);  // lanes >= PPT hold ~0
-      unsigned long long eq = __ballot(sval == wm);
-      if (__popcll(eq) > 1) {  // equal densities in several slots: the smaller low wins
-        const unsigned cand = sval == wm ? slow : 0xffffffffu;
-        eq = __ballot(cand == wave_min_u32(cand));
-      }
-      const int istar = (int)__builtin_ctzll(eq);
-      const unsigned wl = (unsigned)__builtin_amdgcn_readlane((int)slow, istar);
-      const int wo = __builtin_amdgcn_readlane(sown, istar);
-      const unsigned wsec = wave_min_u32(lane == istar ? ssec : sval);
-      if (lane == 0) {
-        const float wx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sx), istar));
-        const float2 q = reinterpret_cast<const float2 *>(yz)[istar * 1024 + wave * 64 + wo];
-        wave_val[buf][wave] = wm;
-        wave_sec[buf][wave] = wsec;
-        wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
-      }
-      __syncthreads();
-      // every wave: the K smallest of the 16 keys, in order (every row of 16 lanes holds the same 16 entries)
-      const int l16 = lane & 15;
-      const unsigned v16 = wave_val[buf][l16], s16 = wave_sec[buf][l16];
-      pk = wave_pick[buf][l16];
-      lw16 = __float_as_uint(pk.w);
-      buf ^= 1;
-      unsigned cv = v16;
-      int valid = 0;
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        const unsigned minv = row_min_u32(cv);
-        const unsigned lwk = cv == minv ? lw16 : 0xffffffffu;
-        const unsigned minl = row_min_u32(lwk);
-        sel[k] = (int)__builtin_ctzll(__ballot(cv == minv && lwk == minl)) & 15;
-        if ((unsigned)__builtin_amdgcn_readfirstlane((int)minv) < kBig) valid = k + 1;  // keys below 1e9 come first
-        if (l16 == sel[k]) cv = 0xffffffffu;
-      }
-      npick = 1;
-      from_table = valid > 0;
-      if (valid == 0) {  // nothing below 1e9: the reference's threads all report (1e9, index 0), and update around it
-        if (tid == 0) out[j] = 0;
-        ++j;
-        continue;
-      }
-      // Which of the candidates 2 .. K follow pick 1?  Lane p < K (K - 1) / 2 tests the pair (a, b), a < b, of the
-      // ORDERED candidates: does pick a leave candidate b alone, and does wave a hold nothing else below b?
-      if (valid > 1 && j + 1 < m) {
-        // pairs in the order (0,1) (0,2) (1,2) (0,3) (1,3) (2,3): pair p belongs to candidate b = 1, 2, 2, 3, 3, 3
-        const int pb = lane == 0 ? 1 : (lane <= 2 ? 2 : 3);
-        const int pa = lane == 0 ? 0 : (lane <= 2 ? lane - 1 : lane - 3);
-        int la = sel[0], lb = sel[K - 1];
-#pragma unroll
-        for (int k = 1; k < K; ++k) {
-          la = pa == k ? sel[k] : la;
-          lb = pb == k ? sel[k] : lb;
-        }
-        const float ax = __shfl(pk.x, la), ay = __shfl(pk.y, la), az = __shfl(pk.z, la);
-        const unsigned as = __shfl(s16, la);
-        const float bx = __shfl(pk.x, lb), by = __shfl(pk.y, lb), bz = __shfl(pk.z, lb);
-        const unsigned bv = __shfl(v16, lb), bl = __shfl(lw16, lb);
-        const float dx = bx - ax, dy = by - ay, dz = bz - az;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
-        const float vb = __uint_as_float(bv);
-        const bool bad = (vb + __builtin_ldexpf(e, (int)(bl & 1u))) != vb || !(as > bv);
-        const unsigned badm = (unsigned)__ballot(bad && lane < K * (K - 1) / 2);
-        // candidate b follows iff candidates 1 .. b-1 did and none of its pairs is bad
-        const int room = m - j;  // picks still wanted
-        if (!(badm & 1u) && room > 1) {
-          npick = 2;
-          if (K > 2 && !(badm & 6u) && valid > 2 && room > 2) {
-            npick = 3;
-            if (K > 3 && !(badm & 56u) && valid > 3 && room > 3) npick = 4;
-          }
-        }
-      }
-#ifdef SN_MDS_STATS
-      if (tid == 0 && b == 0) {
-        atomicAdd(&g_mds_rounds[npick], 1ull);
-        atomicAdd(&g_mds_rounds[5], (unsigned long long)valid);
-      }
-#endif
-      if (tid == 0)
-        for (int r = 0; r < npick; ++r) {
-          const int sl = r == 0 ? sel[0] : (r == 1 ? sel[1 < K ? 1 : 0] : (r == 2 ? sel[2 < K ? 2 : 0] : sel[K - 1]));
-          out[j + r] = (int)(((unsigned)__builtin_amdgcn_readlane((int)lw16, sl) >> 1) & 0x7fffu);
-        }
-      j += npick;
-    }
-    return;
-  }
-#endif
-#if SN_MDS_LAZY
-  // Lazy summaries (round 5).  A round is bound by the instructions it issues, not by its hand-offs (several picks per
-  // round -- above -- bought nothing: the work per PICK stayed), and the summary of an updated slot (three wave
-  // reductions, a logarithm) is two thirds of a slot's update.  Densities only grow, so the old summary of an updated
-  // slot remains a LOWER BOUND of its smallest key: the slot is marked dirty and summarised only when that bound is
-  // the smallest of the wave's -- when its real minimum could be the wave's candidate.  A slot whose smallest entry
-  // did not move at all (the increment was absorbed by the rounding: the rim of the ball) keeps a valid summary:
-  // every other entry was above it and has not fallen.  The stale reach (from the old, smaller minimum) is larger,
-  // never smaller, than the true one.
-  unsigned sdirty = 0;  // lane i: slot i's summary is a lower bound only
-#endif
   for (int j = 1; j < m; ++j) {
     // which slots of this wave can the pick still change?
     const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
     const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
     const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
     const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < reach2);
-#if SN_MDS_LAZY
-    unsigned moved = 0;  // slots whose smallest entry changed
-#endif
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
       if ((mask >> i) & 1u) {  // wave-uniform
@@ -659,34 +431,10 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
         const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
         // points k >= 8192 receive e + e (reference MDS.cu:86-91); doubling is exact
         const float nv = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
-#if SN_MDS_LAZY
-        // did the entry that the (clean) summary names move?  (a dirty slot stays dirty)
-        const int own = __builtin_amdgcn_readlane(sown, i);
-        const unsigned was = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tmp[i]), own);
-        const unsigned now = (unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(nv), own);
-        moved |= (was != now ? 1u : 0u) << i;
-        tmp[i] = nv;
-#else
         tmp[i] = nv;
         summarize(i, __float_as_uint(tmp[i]), low[i], px[i]);
-#endif
       }
     }
-#if SN_MDS_LAZY
-    if ((moved >> lane) & 1u) sdirty = 1u;  // lanes >= 32 hold no slot (PPT <= 19)
-    for (;;) {  // refresh the dirty slots whose bound is the wave's smallest
-      const unsigned lo_ = wave_min_u32(sval);
-      const unsigned long long dm = __ballot(sval == lo_ && sdirty != 0u);
-      if (dm == 0ull) break;
-      const int is = (int)__builtin_ctzll(dm);
-#pragma unroll
-      for (int i = 0; i < PPT; ++i)
-        if (i == is) {  // wave-uniform
-          summarize(i, __float_as_uint(tmp[i]), low[i], px[i]);
-          if (lane == i) sdirty = 0u;
-        }
-    }
-#endif
     // Arg-min of (density, bitrev, k) inside the wave = the smallest slot summary.
     const unsigned wm = wave_min_u32(sval);  // lanes >= PPT hold ~0
     unsigned long long eq = __ballot(sval == wm);
@@ -1185,7 +933,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
         const int pg = (ppt + team_g - 1) / team_g;
         unsigned *sticky = sn::sticky_device_word(dev);
         // SN_MDS_DIAG=8 (tests): the second member of cloud 0's team leaves at once and the polls give up early
-        const char *dg = getenv("SN_MDS_DIAG");
+        const char *dg = SN_KNOB("SN_MDS_DIAG");
         const bool park = dg && atoi(dg) == 8;
         SN_REQUIRE(team_slots * team_g <= 1024, "sn_mds: unexpected team geometry");
         SN_HIP(hipMemsetAsync(tctl, 0, 128 + 128 * 3 * (size_t)team_slots * team_g, s));

@@ -24,6 +24,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "wave_dpp.hpp"
 
 namespace {
 
@@ -540,18 +541,9 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     for (int k = 0; k < NR; ++k) {
       if (!dirty[k]) continue;
       dirty[k] = false;
-      // float minimum over the wave with the DPP modifier ON the v_min (six instructions: four steps inside the rows
-      // of 16 lanes, row_bcast:15 / row_bcast:31 across them; lane 63 ends up with the minimum).  The values are
-      // finite; pixels outside the image take part as +3e38.  "s_nop 1": a DPP operand written by the previous
-      // vector instruction needs two wait states, which nobody inserts inside inline assembly.
-      float m = valid ? b1[k] : 3.0e38f;
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(m));
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(m));
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(m));
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(m));
-      asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(m));
-      tile_min[k] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+      // float minimum over the wave (wave_dpp.hpp: six v_min_f32_dpp + one v_readlane).  The values are finite;
+      // pixels outside the image take part as +3e38.
+      tile_min[k] = sn::wave_min_f32(valid ? b1[k] : 3.0e38f);
     }
   };
 #pragma unroll

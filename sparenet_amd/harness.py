@@ -120,9 +120,12 @@ class Completion(torch.nn.Module):
         cloud of the batch is its own auction, so dist / assignment / gradients are those of the separate calls bit
         for bit) -- one persistent launch instead of three: 3 x 1.06 ms -> 1.3 ms at 4 clouds per rank on a trained
         generator's clouds, 3 x 8.0 -> ~12 ms on an untrained one's."""
-        if self.metric == "chamfer" or len(clouds) == 1 or not self.batch_terms:
-            return [self._metric(c, gt) for c in clouds]
         b = gt.shape[0]
+        # emdModule takes at most 512 clouds per call (cuda/emd/emd_module.py:38): a per-rank batch above 512 / 3
+        # goes back to one call per term.  The batched call's workspace and its ground-truth copy are len(clouds) x
+        # those of one term (gt.repeat: 3 x 6.3 MB at 32 clouds of 16384 points; the workspace 3 x ~59 MB).
+        if self.metric == "chamfer" or len(clouds) == 1 or not self.batch_terms or len(clouds) * b > 512:
+            return [self._metric(c, gt) for c in clouds]
         dist, _ = self.emd_dist(torch.cat(clouds, 0), gt.repeat(len(clouds), 1, 1), eps=0.005, iters=50)
         return [emd_term(dist[i * b:(i + 1) * b]) for i in range(len(clouds))]
 

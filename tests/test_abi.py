@@ -43,7 +43,7 @@ def test_argument_validation_without_gpu():
                                     ctypes.c_size_t(1 << 20), null) == -22
     assert b"power of two" in lib.sn_last_error()
     assert lib.sn_mds(one, 1, 10, 20, one, one, null, ctypes.c_size_t(0), null) == -22
-    ctl = 4 * (32 + 32 * 1024) + 8 * (16 + 64 * 64)   # persistent auction: barrier counters + diag words
+    ctl = 4 * (32 + 2 * 32 * 1024) + 8 * (16 + 64 * 64)   # persistent auction: barrier counters, note blocks + diag words
     # 14 word arrays + 2 arrays of 8-byte entries ({index, rank} lists, {price, index} stream) + 3 of 16-byte entries
     # (bid records {increment, next, index, -}, target records, matrix-core operands) + ...
     assert lib.sn_emd_workspace_bytes(32, 16384) == (14 * 32 * 16384 * 4 + 2 * 32 * 16384 * 8 + 2 * 32 * 256 * 4

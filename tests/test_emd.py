@@ -116,6 +116,30 @@ def test_hip_matches_golden(golden_dir, dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("skip,spread,scan", [("0", "0", None), ("2", "2", None), ("1", "3", None), ("2", "0", "1000000"),
+                                              ("0", "2", "0")])
+def test_hip_forced_paths_match_emulated_reference_golden(skip, spread, scan, golden_dir, dev, monkeypatch):
+    """Round 5's data-dependent auction paths against the REFERENCE'S kernel text (the emulated goldens, which include
+    contested geometries: targets on a sphere, bidders scattered through the cube around it, eps > 0 and < 0), not
+    only against oracle/emd.c: the outbid-skip (SN_EMD_SKIP 0 = never, 2 = every iteration), the transposed rank split
+    (SN_EMD_SPREAD 0 / 2 / 3) and both bid forms (SN_EMD_SCAN 0 = matrix-core search only, 10^6 = scan from the
+    first iteration), each forced on and off."""
+    monkeypatch.setenv("SN_EMD_SKIP", skip)
+    monkeypatch.setenv("SN_EMD_SPREAD", spread)
+    if scan is not None:
+        monkeypatch.setenv("SN_EMD_SCAN", scan)
+    seen_contested = 0
+    for f in _golden(golden_dir):
+        z = np.load(f)
+        seen_contested += "contested" in os.path.basename(f)
+        d, a, st = _hip(z["xyz1"], z["xyz2"], float(z["eps"]), int(z["iters"]), dev, stats=True)
+        assert np.array_equal(a, z["assignment"]), (f, skip, spread, scan)
+        assert np.array_equal(d, z["dist"]), (f, skip, spread, scan)
+        assert st[0] == int(z["unass"].astype(np.int64).sum()) * z["xyz1"].shape[1], (f, skip, spread, scan)
+    assert seen_contested >= 4
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("b,n,iters,eps,kind,seed", [
     (3, 1024, 7, 0.005, "uniform", 1),
     (2, 2048, 12, 0.002, "uniform", 2),
@@ -261,3 +285,33 @@ def test_hip_full_size_properties(dev):
     m = float(torch.sqrt(d).mean())
     assert 0.01 < m < 0.05, m
     assert int(st[0]) >= 32 * 16384 * 16384
+
+
+def _racy_golden(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, "xfail_emd_*.npz")))
+
+
+def test_oracle_matches_canonical_run_of_schedule_dependent_golden(golden_dir):
+    """Fixtures on which the reference's OWN kernels race (several bidders inside GetMax's +-1e-6 window,
+    emd_cuda.cu:188-191: the last writer wins) are kept as xfail_emd_*.npz with the CANONICAL run (threads started in
+    order -- the sequential ascending-j order the oracle and the HIP kernel implement).  The oracle must reproduce
+    that run; that other schedules give other results is the reference's race, recorded in the fixture."""
+    files = _racy_golden(golden_dir)
+    for f in files:
+        z = np.load(f)
+        assert not bool(z["schedule_invariant"])
+        if "agrees_with_oracle" in z.files and not bool(z["agrees_with_oracle"]):
+            continue   # a fixture the oracle's rule does not explain stays an expected failure (none today)
+        d, a, aux = oracle.emd_forward(z["xyz1"], z["xyz2"], float(z["eps"]), int(z["iters"]), return_aux=True)
+        assert np.array_equal(a, z["assignment"]) and np.array_equal(d, z["dist"]), f
+        assert np.array_equal(aux["unass"], z["unass"]), f
+
+
+@pytest.mark.gpu
+def test_hip_matches_canonical_run_of_schedule_dependent_golden(golden_dir, dev):
+    for f in _racy_golden(golden_dir):
+        z = np.load(f)
+        if "agrees_with_oracle" in z.files and not bool(z["agrees_with_oracle"]):
+            continue
+        d, a = _hip(z["xyz1"], z["xyz2"], float(z["eps"]), int(z["iters"]), dev)
+        assert np.array_equal(a, z["assignment"]) and np.array_equal(d, z["dist"]), f

@@ -93,3 +93,28 @@ def test_batched_emd_terms_equal_the_three_calls(dev):
     (l1, r1, c1, g1), (l2, r2, c2, g2) = res
     assert torch.equal(l1, l2) and torch.equal(r1, r2) and torch.equal(c1, c2)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+
+
+def test_batched_emd_terms_fall_back_above_512_clouds():
+    """emdModule takes at most 512 clouds per call (cuda/emd/emd_module.py:38): three terms of a per-rank batch above
+    170 clouds go back to one auction call per term instead of failing the assert (advisor, round 5)."""
+    from sparenet_amd.harness import Completion
+
+    calls = []
+
+    class FakeEmd(torch.nn.Module):
+        def forward(self, a, b, eps, iters):
+            assert a.shape[0] <= 512 and a.shape == b.shape
+            calls.append(a.shape[0])
+            return (a - b).pow(2).sum(-1), None
+
+    comp = Completion("emd")
+    comp.emd_dist = FakeEmd()
+    for b, expect in ((170, [510]), (171, [171, 171, 171]), (512, [512, 512, 512])):
+        calls.clear()
+        gt = torch.rand(b, 8, 3)
+        clouds = [torch.rand(b, 8, 3) for _ in range(3)]
+        terms = comp._metrics(clouds, gt)
+        assert calls == expect and len(terms) == 3
+        for c, t in zip(clouds, terms):
+            assert torch.equal(t, comp._metric(c, gt))
