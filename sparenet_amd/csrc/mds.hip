@@ -29,6 +29,30 @@
 // against 18.4) and lazy slot summaries (25.6 ms against 18.3) -- were index-exact and slower; they live in the git
 // history (commit 255d4b0 and before) and in profiles/r05_c_mds_rounds_not_kept.txt, not in this file.
 
+#ifdef SN_MDS_STAMPS   // experiment builds (tools/build_variant.sh stamps mds.hip -DSN_MDS_STAMPS): where a round of the
+                       // dense-regime team kernel spends its time, wave 0 of member 0 of cloud 0, 100 MHz ticks:
+                       // [0] update + arg-min in the wave, [1] first workgroup barrier (waiting for the slowest wave),
+                       // [2] store + poll of the team's words, [3] minimum + the pick's coordinates (uniform load),
+                       // [4] second workgroup barrier + hand-over, [5] rounds
+__device__ unsigned long long g_mds_stamps[8];
+extern "C" int sn_mds_debug_stamps(unsigned long long *out8, int reset) {
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mds_stamps), 64) != hipSuccess) return -1;
+  if (reset) {
+    unsigned long long z[8] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_mds_stamps), z, 64) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#define MDS_STAMP(i)                                                                    \
+  if (stamping) {                                                                       \
+    const long long now_ = (long long)__builtin_amdgcn_s_memrealtime();                 \
+    st_acc[i] += now_ - st_tk;                                                          \
+    st_tk = now_;                                                                       \
+  }
+#else
+#define MDS_STAMP(i)
+#endif
+
 namespace {
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m, int width) {
@@ -642,6 +666,11 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     __syncthreads();
   }
 
+#ifdef SN_MDS_STAMPS
+  const bool stamping = b == 0 && g == 0 && wave == 0;
+  long long st_acc[6] = {0, 0, 0, 0, 0, 0};
+  long long st_tk = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
   for (int j = 1; j < m; ++j) {
     const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
     const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
@@ -680,7 +709,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
       const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
       wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
     }
+    MDS_STAMP(0)
     __syncthreads();
+    MDS_STAMP(1)
     const int l16 = lane & 15;
     const unsigned v16 = wave_val[buf][l16];
     const float4 pk = wave_pick[buf][l16];
@@ -723,6 +754,7 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
           }
         }
       }
+      MDS_STAMP(2)
       const bool stale = lane < G && (unsigned)(w & 63ull) != (unsigned)(j & 63);
       unsigned long long key = lane < G ? (w >> 6) : ~0ull;
 #pragma unroll
@@ -742,8 +774,13 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
         s_pick[buf] = make_float4(px_, py_, pz_, __uint_as_float(val >= kBig ? 0u : lw2));
         s_state[buf] = any_stale ? -1 : (val >= kBig ? 0 : 1);
       }
+#ifdef SN_MDS_STAMPS
+      if (stamping) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
+      MDS_STAMP(3)
     }
     __syncthreads();
+    MDS_STAMP(4)
     const int state = s_state[buf];
     if (state < 0) {  // a member never answered (workgroup-uniform): the WHOLE row becomes -1 -- a partial sequence
       if (g == 0)     // would look like a result; sn_gather_forward turns -1 into NaN, the next sn_mds call fails
@@ -760,6 +797,12 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     }
     if (tid == 0 && g == 0) out[j] = last;
   }
+#ifdef SN_MDS_STAMPS
+  if (stamping && lane == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(&g_mds_stamps[i], (unsigned long long)st_acc[i]);
+    atomicAdd(&g_mds_stamps[5], (unsigned long long)(m - 1));
+  }
+#endif
 }
 
 // generic fallback for clouds that do not fit the register budget: state in global memory

@@ -1091,10 +1091,15 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     if (has) {
       // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
       // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
+#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 4
+      const float py = (float)(pid & 255), px = (float)((pid >> 8) & 255);
+      const float fv = (float)(pid & 15);
+#else
       const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+      const float fv = feat[(size_t)pid * channels + c];
+#endif
       const float dx = x - px, dy = y - py;
       const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
-      const float fv = feat[(size_t)pid * channels + c];
       const float cf = gk * weight32(u);
       const float kk = gk * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
       t0 = fixed(cf);
@@ -1107,6 +1112,10 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     // instruction): exact, and no faster -- 491.9 -> 494.1 us at 8 views x 32 clouds.  The kernel's time is the ~45
     // GLOBAL 8-byte atomics per tile (11.8 M per launch), not the table; removed.)
     if (!live) continue;
+#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 3
+    bg += (float)(t0 ^ t1 ^ t2);
+    continue;
+#endif
     unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
     bool found = false;
     for (int probe = 0; probe < kAccProbes; ++probe) {
@@ -1117,6 +1126,10 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
       }
       slot = (slot + 1) & (kAccSlots - 1);
     }
+#if defined(SN_ACC_EXP) && SN_ACC_EXP == 2
+    bg += (float)(t0 ^ t1 ^ t2) + (float)found;
+    continue;
+#endif
     if (found) {
       atomicAdd(&vals[wave][slot][0], t0);
       atomicAdd(&vals[wave][slot][1], t1);
@@ -1128,6 +1141,11 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     }
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 1
+  if (absmax[0] != 0x12345u)
+    for (int i = lane; i < kAccSlots; i += 64) bg += (float)keys[wave][i] + (float)vals[wave][i][0];
+  else
+#endif
   for (int i = lane; i < kAccSlots; i += 64) {
     const int id0 = keys[wave][i];
     if (id0 < 0) continue;

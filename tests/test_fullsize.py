@@ -270,14 +270,13 @@ def test_chamfer_and_expansion_whole_c2_clouds(dev):
 
 @pytest.mark.gpu
 def test_randomised_sweep_at_large_sizes(dev):
-    """A time-boxed randomised sweep (tools/fuzz_parity.py's generator) at n in {8192, 16384}:
-    EMD and Chamfer against the oracle, bit-exact, ~60 s."""
-    import time
-
+    """A FIXED list of randomised cases (tools/fuzz_parity.py's generator, the first kFuzzCases draws of one seeded
+    stream: the same cases on every box -- round 5's loop ran for 60 s of wall clock, so its coverage depended on the
+    host) at n in {8192, 16384}: EMD and Chamfer against the oracle, bit-exact."""
+    kFuzzCases = 8
     rng = np.random.default_rng(20260927)
-    t_end = time.time() + 60
     cases = 0
-    while time.time() < t_end:
+    for _case in range(kFuzzCases):
         n = int(rng.choice([8192, 16384]))
         b = int(rng.integers(1, 4))
         kind = str(rng.choice(["uniform", "near", "clustered", "surface", "aniso"]))
@@ -309,7 +308,7 @@ def test_randomised_sweep_at_large_sizes(dev):
         o1, o2, _, _ = oracle.chamfer_forward(x, y, mt=True)
         assert np.array_equal(c1.cpu().numpy(), o1) and np.array_equal(c2.cpu().numpy(), o2), tag
         cases += 1
-    assert cases >= 3
+    assert cases == kFuzzCases
 
 
 @pytest.mark.gpu

@@ -19,7 +19,7 @@ import csv, glob, json, sys
 kernels = ["emd_auction_kernel", "emd_seed_kernel", "emd_init_kernel", "cloud_sort_count_kernel",
            "nn_search_kernel", "chamfer_bwd_lists_kernel", "chamfer_bwd_gather_kernel", "expansion_fwd_kernel",
            "p2i_gather_max_kernel", "p2i_max_bwd_accum_kernel", "p2i_bin_grouped_kernel", "p2i_absmax_kernel",
-           "depth_project_views_kernel", "mds_clustered_kernel"]
+           "depth_project_views_kernel", "mds_clustered_kernel", "mds_dense_team_kernel"]
 res = {k: {} for k in kernels}
 for d in ("pmcA", "pmcB", "pmcC", "pmcD"):
     fs = glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True)

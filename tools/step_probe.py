@@ -52,4 +52,11 @@ if os.environ.get("PROBE_MDS", "1") != "0":
     cloud_s = torch.cat([surf, surf[:, :3000] + 0.01 * torch.randn(B, 3000, 3, generator=g).to(dev)], 1).contiguous()
     minimum_density_sample(cloud_s, N, mml_s)
     torch.cuda.synchronize()
+if os.environ.get("PROBE_MDS_DENSE", "1") != "0":
+    # the DENSE regime (the cut ball covers the cloud: a team of workgroups per cloud, mds_dense_team_kernel) -- what
+    # the first sampler call of an untrained generator is: uniform cloud, mean MST length 0.05 / 0.0853
+    dense = torch.rand(B, N + 3000, 3, generator=g).to(dev)
+    for bsz in (32, 4):
+        minimum_density_sample(dense[:bsz].contiguous(), N, torch.full((bsz,), 0.05, device=dev))
+    torch.cuda.synchronize()
 print("probe done")
