@@ -166,8 +166,10 @@ class HotPath:
         self.side = None
         self.side2 = None
         self.hi = None
-        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first" / "chain" force an order (A/B); auto: by batch
-        self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: by batch
+        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first" / "chain" / "one_stream" force an order (A/B); auto: MEASURED
+        self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: measured with the order
+        # batch size -> (schedule name, {schedule: ms}) chosen by choose_schedule() during the untimed warm-up
+        self.schedule = {}
 
     def _emd(self, pred, gt):
         """emdFunction with the effective-pair counter attached."""
@@ -215,6 +217,8 @@ class HotPath:
         teams leave half of the chip idle, but running renderer + expansion + Chamfer beside it made the step
         SLOWER whichever side was enqueued first: 2.52-2.54 vs 2.26 ms at 4 clouds, 2.86 vs 2.54 at 8.)"""
         main = torch.cuda.current_stream()
+        if self.one_stream(pred.size(0)):   # measured: no overlapped order beats the plain sequence at this batch size
+            return self.step(pred, gt)
         if self.auction_first(pred.size(0)):
             return self._step_auction_first(pred, gt, main)
         if self.side is None:
@@ -254,9 +258,47 @@ class HotPath:
         expansion | Chamfer -> auction with the renderer beside it stays (16 / 8 / 4 clouds: 3.18 / 1.96 / 1.54-1.65 ms
         against 3.16-3.45 / 2.01 / 1.78: the auction's teams leave XCDs idle there, and the chain's head overlaps the
         renderer)."""
-        if self.order in ("auction_first", "chain"):
+        if self.order in ("auction_first", "chain", "one_stream"):
             return self.order == "auction_first"
-        return clouds >= 24
+        if clouds in self.schedule:
+            return self.schedule[clouds][0] == "auction_first"
+        return clouds >= 24   # before / without choose_schedule(): round 4's table
+
+    def one_stream(self, clouds):
+        if self.order != "auto":
+            return self.order == "one_stream"
+        return clouds in self.schedule and self.schedule[clouds][0] == "one_stream"
+
+    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first")
+
+    def choose_schedule(self, pred, gt, reps=6, reduce_max=None):
+        """Time every schedule on THIS batch during the untimed warm-up and keep the fastest (round 5 shipped a constant
+        threshold -- auction first from 24 clouds on, a third stream up to 16 -- under which the 16-cloud share of the
+        strong split ran 4.07 ms against 3.32 for its own one-stream sequence).  Per schedule: 2 untimed + `reps` timed
+        steps between synchronisations, wall clock (what the timed region measures).  The plain one-stream sequence is a
+        candidate, so the step is never slower than it by choice.  reduce_max: callable that max-reduces a list of
+        floats over the ranks (every rank then picks the same schedule); None on one rank.  BENCH_ORDER /
+        BENCH_THREE_STREAMS still force an order (A/B)."""
+        clouds = pred.size(0)
+        if self.order != "auto" or self.three_streams_env in ("0", "1") or clouds in self.schedule:
+            return self.schedule.get(clouds)
+        table = {}
+        for name in self.SCHEDULES:
+            self.schedule[clouds] = (name, None)
+            for _ in range(2):
+                self.step_overlapped(pred, gt)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                self.step_overlapped(pred, gt)
+            torch.cuda.synchronize()
+            table[name] = (time.perf_counter() - t0) / reps * 1e3
+        if reduce_max is not None:
+            vals = reduce_max([table[k] for k in self.SCHEDULES])
+            table = dict(zip(self.SCHEDULES, vals))
+        best = min(self.SCHEDULES, key=lambda k: table[k])
+        self.schedule[clouds] = (best, table)
+        return self.schedule[clouds]
 
     def _step_auction_first(self, pred, gt, main):
         """The auction on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two
@@ -291,7 +333,9 @@ class HotPath:
         two-stream step is kept, so that the roofline's live duration stays the kernel's."""
         if self.three_streams_env in ("0", "1"):
             return self.three_streams_env == "1"
-        return clouds <= 16
+        if clouds in self.schedule:
+            return self.schedule[clouds][0] == "chain_3"
+        return clouds <= 16   # before / without choose_schedule(): round 3's table
 
     def _loss_expansion(self, pred):
         # one wave per 512-point patch = lone waves for 0.35-0.45 ms, latency bound: next to another stream's work
@@ -345,9 +389,11 @@ class HotPath:
         return losses
 
 
-def timed_region(hp, pred, gt, steps, warmup, overlap, barrier, before_timed=lambda: None):
+def timed_region(hp, pred, gt, steps, warmup, overlap, barrier, before_timed=lambda: None, reduce_max=None):
     """W untimed + exactly K timed steps between barrier + synchronize; returns (seconds, per-step ms, losses)."""
     run_step = hp.step_overlapped if overlap else hp.step
+    if overlap:   # untimed: which stream order is fastest on this batch (kept per batch size)
+        hp.choose_schedule(pred, gt, reduce_max=reduce_max)
     for _ in range(warmup):
         run_step(pred, gt)
     barrier()
@@ -781,13 +827,20 @@ def main():
 
     overlap = not args.no_overlap
 
+    def reduce_max(vals):   # every rank keeps the same schedule: the slowest rank's time decides
+        if world == 1:
+            return vals
+        t = torch.tensor(vals, dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t.tolist()]
+
     def prof_on():   # the in-library launch timers cover exactly the timed steps
         if not args.no_roofline:
             lib.sn_prof_reset()
             lib.sn_emd_prof_exec(None, 1)
             lib.sn_prof_enable(1)
 
-    elapsed, per_step, losses = timed_region(hp, pred, gt, args.steps, args.warmup, overlap, barrier, prof_on)
+    elapsed, per_step, losses = timed_region(hp, pred, gt, args.steps, args.warmup, overlap, barrier, prof_on, reduce_max)
     lib.sn_prof_enable(0)
     hp.lib.check(lib.sn_device_status(), "timed region")   # a team barrier that gave up inside it (NaN losses) is an error
     stats_timed = hp.stats.clone()
@@ -841,7 +894,7 @@ def main():
     if world > 1 and not args.no_other_scaling:
         mode2 = "strong" if args.scaling == "weak" else "weak"
         p2_, g2_ = make_inputs(dev, rank, world, mode2)
-        e2, ps2, _ = timed_region(hp, p2_, g2_, args.steps, args.warmup, overlap, barrier)
+        e2, ps2, _ = timed_region(hp, p2_, g2_, args.steps, args.warmup, overlap, barrier, reduce_max=reduce_max)
         t2 = torch.tensor([e2], dtype=torch.float64, device=dev)
         pe2 = hp.stats[0:1].to(torch.float64)
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
@@ -865,7 +918,7 @@ def main():
         lsteps = min(args.steps, 20)
         # >= 10 warm-up steps: a new HotPath, another template instance of the gather (2 radii) and fresh allocator
         # blocks made the first timed steps of this region 5-8x slower than the rest in round 3 (max 28 ms, median 3.4)
-        e3, ps3, _ = timed_region(hp2, pred, gt, lsteps, max(args.warmup, 10), overlap, barrier)
+        e3, ps3, _ = timed_region(hp2, pred, gt, lsteps, max(args.warmup, 10), overlap, barrier, reduce_max=reduce_max)
         t3 = torch.tensor([e3], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(t3, op=dist.ReduceOp.MAX)
@@ -1067,9 +1120,13 @@ def main():
                 "batch_per_gpu": b_local, "global_batch": b_local * world, "points": N,
                 "emd_iters": EMD_ITERS, "radius_list": radius_list,
                 "image": IMG, "views": N_VIEWS,
-                "streams": (3 if (hp.three_streams(b_local) or hp.auction_first(b_local)) else 2) if overlap else 1,
-                "order": ("auction first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_first(b_local)
+                "streams": (1 if hp.one_stream(b_local) else
+                            (3 if (hp.three_streams(b_local) or hp.auction_first(b_local)) else 2)) if overlap else 1,
+                "order": ("one stream" if hp.one_stream(b_local) else
+                          "auction first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_first(b_local)
                           else "expansion | Chamfer -> auction, renderer beside") if overlap else "one stream",
+                # the stream orders timed on this batch during the untimed warm-up (HotPath.choose_schedule): ms per step
+                "schedule_table_ms": (hp.schedule.get(b_local) or (None, None))[1],
                 "library_build": build_id,
                 "render": "view by view" if args.per_view_render else "8 views in one pass (forward_views)",
             },

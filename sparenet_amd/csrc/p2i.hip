@@ -1031,50 +1031,55 @@ __device__ __forceinline__ double fixed_scale(const unsigned *absmax, float min_
 }
 
 #ifndef SN_ACC_SLOTS
-#define SN_ACC_SLOTS 128
+#define SN_ACC_SLOTS 512
 #endif
-constexpr int kAccSlots = SN_ACC_SLOTS;  // per-wave hash table.  A tile can have up to 64 x 4 distinct winners, real
-                                         // tiles have ~15: a term that finds no slot within kAccProbes steps goes
-                                         // straight to the global accumulators, and the smaller table (3.5 KB per
-                                         // wave instead of 7) lets 8 workgroups share a CU instead of 5
-constexpr int kAccProbes = 16;
+#ifndef SN_ACC_REGION
+#define SN_ACC_REGION 4   // tiles per side of a workgroup's region (4: 32 x 32 pixels)
+#endif
+constexpr int kAccSlots = SN_ACC_SLOTS;  // per-WORKGROUP hash table of the winners of a region (real regions of 32 x 32
+                                         // pixels hold ~120 distinct winners over three radii; a term that finds no slot
+                                         // within kAccProbes steps goes straight to the global accumulators -- integer
+                                         // sums are exact in any order): 14 KB of LDS, 8 workgroups per CU
+constexpr int kAccProbes = 8;
+constexpr int kAccRegion = SN_ACC_REGION;
 
+// One WORKGROUP per region of kAccRegion x kAccRegion tiles of 8 x 8 pixels (wave w walks down column w of the region:
+// at any time the four waves read four horizontally adjacent tiles), one hash table per workgroup, ONE flush per
+// region.  Round 6, from the experiment matrix of profiles/r06_a_render_accum_experiments.txt (8 views x 32 clouds x 3
+// radii: the kernel's 0.49 ms = 0.20 global flush + 0.11 LDS adds + 0.07 dependent gathers + 0.11 streaming): a point
+// wins pixels in 2.8 tiles of 8 x 8 on average, so a table per tile (rounds 1-5: 128 slots per wave) sent 2.8 triples
+// of 64-bit global atomics per winning point (11.8 M atomics per launch); a region of 32 x 32 pixels holds most
+// winners' whole footprint.
 __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     const float *__restrict__ out_grad, const int *__restrict__ out_ids,
     const float *__restrict__ points, const float *__restrict__ feat,
     const unsigned *__restrict__ absmax, float *__restrict__ background_grad,
     long long *__restrict__ acc_pts, long long *__restrict__ acc_feat, int channels, int batch,
     int h, int w, RadiiArg ra, int nradii, float min_radius, long obstride, long orstride) {
-  // One wave per 8x8 tile (lane = pixel).  Neighbouring pixels, and the radii of one pixel,
-  // often share their winner: the terms first meet in a per-wave LDS hash table keyed by the
-  // point id (LDS integer atomics), and every distinct winner of the tile then costs three
-  // global atomics.  XCD-aware: workgroup g runs on XCD g % 8 and only touches images b with
-  // b % 8 == g % 8.
-  __shared__ int keys[4][kAccSlots];
-  __shared__ unsigned long long vals[4][kAccSlots][3];
+  // lane = pixel of an 8 x 8 tile.  Neighbouring pixels, and the radii of one pixel, often share their winner: the
+  // terms first meet in the workgroup's LDS hash table keyed by the point id (LDS integer atomics), and every distinct
+  // winner of the region then costs three global atomics.  XCD-aware: workgroup g runs on XCD g % 8 and only touches
+  // images b with b % 8 == g % 8.
+  __shared__ int keys[kAccSlots];
+  __shared__ unsigned long long vals[kAccSlots][3];
   const int cells_x = (w + kCell - 1) / kCell, cells_y = (h + kCell - 1) / kCell;
-  const long per_image = (long)channels * cells_y * cells_x;  // tiles
-  const int bpi = (int)((per_image + 3) / 4);                  // workgroups per image
+  const int regs_x = (cells_x + kAccRegion - 1) / kAccRegion, regs_y = (cells_y + kAccRegion - 1) / kAccRegion;
+  const int rpi = channels * regs_y * regs_x;                  // regions (= workgroups) per image
   const int g = blockIdx.x, xcd = g & 7, r = g >> 3;
-  const int b = (r / bpi) * 8 + xcd;
+  const int b = (r / rpi) * 8 + xcd;
+  if (b >= batch) return;  // whole workgroups
+  int reg = r % rpi;
+  const int rx = reg % regs_x; reg /= regs_x;
+  const int ry = reg % regs_y;
+  const int c = reg / regs_y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  long tile = (long)(r % bpi) * 4 + wave;
-  if (b >= batch || tile >= per_image) return;  // whole waves; no workgroup barrier below
-  const int cx = (int)(tile % cells_x); tile /= cells_x;
-  const int cy = (int)(tile % cells_y);
-  const int c = (int)(tile / cells_y);
-  const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
-  const bool valid = x < w && y < h;
   const double scale = fixed_scale(absmax, min_radius);
   const size_t plane = ((size_t)b * channels + c) * h * w;
-  const size_t e = plane + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
-  const size_t oe = (size_t)b * obstride + (size_t)c * h * w + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
-  for (int i = lane; i < kAccSlots; i += 64) {
-    keys[wave][i] = -1;
-    vals[wave][i][0] = vals[wave][i][1] = vals[wave][i][2] = 0ull;
+  for (int i = threadIdx.x; i < kAccSlots; i += 256) {
+    keys[i] = -1;
+    vals[i][0] = vals[i][1] = vals[i][2] = 0ull;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  float bg = 0.f;
+  __syncthreads();
   // llrint(x * scale) through the 1.5 * 2^52 trick: scale is a power of two (the product is exact) and every
   // |term| < 2^44, so rn(x * scale + 1.5 * 2^52) carries rint(x * scale) in its low mantissa bits -- the same
   // integer as llrint under round-to-nearest-even, in 4 instructions instead of the library's 8 fp64 ones per term
@@ -1082,78 +1087,72 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     const double m = 6755399441055744.0;  // 1.5 * 2^52
     return (unsigned long long)(__double_as_longlong(__builtin_fma((double)x, scale, m)) - __double_as_longlong(m));
   };
-  for (int k = 0; k < nradii; ++k) {
-    const float gk = valid ? out_grad[(size_t)k * orstride + oe] : 0.f;
-    const int pid = valid ? out_ids[(size_t)k * orstride + oe] : -1;
-    const bool has = pid >= 0;
-    if (!has) bg += gk;
-    unsigned long long t0 = 0ull, t1 = 0ull, t2 = 0ull;
-    if (has) {
-      // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
-      // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
-#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 4
-      const float py = (float)(pid & 255), px = (float)((pid >> 8) & 255);
-      const float fv = (float)(pid & 15);
-#else
-      const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
-      const float fv = feat[(size_t)pid * channels + c];
-#endif
-      const float dx = x - px, dy = y - py;
-      const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
-      const float cf = gk * weight32(u);
-      const float kk = gk * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
-      t0 = fixed(cf);
-      t1 = fixed(kk * dy);
-      t2 = fixed(kk * dx);
-    }
-    bool live = has;
-    // (Round 5 merged the terms of neighbouring pixels with the same winner -- lane ^ 1, then lane ^ 8 -- before the
-    // table's atomics, to take the same-address LDS atomics down (SQ_LDS_BANK_CONFLICT 11.7 cycles per LDS
-    // instruction): exact, and no faster -- 491.9 -> 494.1 us at 8 views x 32 clouds.  The kernel's time is the ~45
-    // GLOBAL 8-byte atomics per tile (11.8 M per launch), not the table; removed.)
-    if (!live) continue;
-#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 3
-    bg += (float)(t0 ^ t1 ^ t2);
-    continue;
-#endif
-    unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
-    bool found = false;
-    for (int probe = 0; probe < kAccProbes; ++probe) {
-      const int prev = atomicCAS(&keys[wave][slot], -1, pid);
-      if (prev == -1 || prev == pid) {
-        found = true;
-        break;
+  for (int ty = 0; ty < kAccRegion; ++ty) {
+    for (int tx = wave; tx < kAccRegion; tx += 4) {
+      const int cx = rx * kAccRegion + tx, cy = ry * kAccRegion + ty;
+      if (cx >= cells_x || cy >= cells_y) continue;  // wave-uniform
+      const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
+      const bool valid = x < w && y < h;
+      const size_t e = plane + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
+      const size_t oe = (size_t)b * obstride + (size_t)c * h * w + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
+      float bg = 0.f;
+      float gk[kMaxRadii];
+      int pidk[kMaxRadii];
+#pragma unroll
+      for (int k = 0; k < kMaxRadii; ++k) {  // the tile's loads go out together
+        gk[k] = (k < nradii && valid) ? out_grad[(size_t)k * orstride + oe] : 0.f;
+        pidk[k] = (k < nradii && valid) ? out_ids[(size_t)k * orstride + oe] : -1;
       }
-      slot = (slot + 1) & (kAccSlots - 1);
-    }
-#if defined(SN_ACC_EXP) && SN_ACC_EXP == 2
-    bg += (float)(t0 ^ t1 ^ t2) + (float)found;
-    continue;
-#endif
-    if (found) {
-      atomicAdd(&vals[wave][slot][0], t0);
-      atomicAdd(&vals[wave][slot][1], t1);
-      atomicAdd(&vals[wave][slot][2], t2);
-    } else {  // a crowded table: integer sums are exact in any order
-      atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)pid * channels + c), t0);
-      atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 0), t1);
-      atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 1), t2);
+#pragma unroll
+      for (int k = 0; k < kMaxRadii; ++k) {
+        if (k >= nradii) break;
+        const int pid = pidk[k];
+        if (pid < 0) {
+          bg += gk[k];
+          continue;
+        }
+        // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
+        // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
+        const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
+        const float fv = feat[(size_t)pid * channels + c];
+        const float dx = x - px, dy = y - py;
+        const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
+        const float cf = gk[k] * weight32(u);
+        const float kk = gk[k] * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
+        const unsigned long long t0 = fixed(cf), t1 = fixed(kk * dy), t2 = fixed(kk * dx);
+        // (Round 5 merged the terms of neighbouring pixels with the same winner -- lane ^ 1, then lane ^ 8 -- before
+        // the table's atomics: exact, and no faster; removed.)
+        unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
+        bool found = false;
+        for (int probe = 0; probe < kAccProbes; ++probe) {
+          const int prev = atomicCAS(&keys[slot], -1, pid);
+          if (prev == -1 || prev == pid) {
+            found = true;
+            break;
+          }
+          slot = (slot + 1) & (kAccSlots - 1);
+        }
+        if (found) {
+          atomicAdd(&vals[slot][0], t0);
+          atomicAdd(&vals[slot][1], t1);
+          atomicAdd(&vals[slot][2], t2);
+        } else {  // a crowded table: integer sums are exact in any order
+          atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)pid * channels + c), t0);
+          atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 0), t1);
+          atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 1), t2);
+        }
+      }
+      if (valid && background_grad) background_grad[e] = bg;
     }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if defined(SN_ACC_EXP) && SN_ACC_EXP >= 1
-  if (absmax[0] != 0x12345u)
-    for (int i = lane; i < kAccSlots; i += 64) bg += (float)keys[wave][i] + (float)vals[wave][i][0];
-  else
-#endif
-  for (int i = lane; i < kAccSlots; i += 64) {
-    const int id0 = keys[wave][i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < kAccSlots; i += 256) {
+    const int id0 = keys[i];
     if (id0 < 0) continue;
-    atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)id0 * channels + c), vals[wave][i][0]);
-    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 0), vals[wave][i][1]);
-    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 1), vals[wave][i][2]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)id0 * channels + c), vals[i][0]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 0), vals[i][1]);
+    atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)id0 * 2 + 1), vals[i][2]);
   }
-  if (valid && background_grad) background_grad[e] = bg;
 }
 
 __global__ __launch_bounds__(256) void p2i_max_bwd_finish_kernel(
@@ -1450,8 +1449,10 @@ extern "C" int sn_p2i_max_backward_multi(const float *out_grad, const int *out_i
   SN_HIP(hipMemsetAsync(workspace, 0, sn_p2i_max_backward_multi_workspace_bytes(npoints, channels), s));
   p2i_absmax_kernel<<<512, 1024, 0, s>>>(out_grad, px * nradii, feat,
                                                            (long)npoints * channels, absmax);
-  const long per_image = (long)channels * sn::ceil_div(h, kCell) * sn::ceil_div(w, kCell);  // tiles
-  const long blocks = (per_image + 3) / 4 * 8 * ((batch + 7) / 8);
+  // one workgroup per region of kAccRegion x kAccRegion tiles; images b with b % 8 == x on XCD x (blockIdx % 8)
+  const long per_image = (long)channels * sn::ceil_div(sn::ceil_div(h, kCell), kAccRegion) *
+                         sn::ceil_div(sn::ceil_div(w, kCell), kAccRegion);
+  const long blocks = per_image * 8 * ((batch + 7) / 8);
   SN_REQUIRE(blocks < (1L << 31), "sn_p2i_max_backward_multi: image too large");
   p2i_max_bwd_accum_kernel<<<(int)blocks, 256, 0, s>>>(out_grad, out_ids, points, feat, absmax,
                                                        background_grad, acc_pts, acc_feat, channels,

@@ -137,11 +137,24 @@ def test_bench_launches_its_own_ranks(monkeypatch):
 
 
 def test_bench_step_schedule_by_batch():
-    """Third stream for the expansion penalty only at <= 16 clouds per rank (bench.HotPath.three_streams)."""
+    """bench.HotPath's stream order: the table of rounds 3-4 before anything was measured (third stream for the expansion
+    penalty at <= 16 clouds per rank, auction first from 24 on), the MEASURED choice afterwards (choose_schedule keeps
+    the fastest of one stream / two / three / auction first per batch size -- never slower than one stream), and the
+    environment overrides for A/B runs."""
     import bench
 
     hp = bench.HotPath.__new__(bench.HotPath)
-    hp.three_streams_env = None
+    hp.three_streams_env, hp.order, hp.schedule = None, "auto", {}
     assert [hp.three_streams(b) for b in (32, 16, 8, 4)] == [False, True, True, True]
+    assert [hp.auction_first(b) for b in (32, 24, 16, 4)] == [True, True, False, False]
+    assert not any(hp.one_stream(b) for b in (32, 16, 8, 4))
+    hp.schedule = {16: ("one_stream", {}), 32: ("auction_first", {}), 8: ("chain_3", {}), 4: ("chain_2", {})}
+    assert [hp.one_stream(b) for b in (32, 16, 8, 4)] == [False, True, False, False]
+    assert [hp.auction_first(b) for b in (32, 16, 8, 4)] == [True, False, False, False]
+    assert [hp.three_streams(b) for b in (32, 16, 8, 4)] == [False, False, True, False]
     hp.three_streams_env = "0"
-    assert not hp.three_streams(4)
+    assert not hp.three_streams(8)
+    hp.order = "chain"
+    assert not hp.auction_first(32) and not hp.one_stream(16)
+    hp.order = "one_stream"
+    assert hp.one_stream(32) and not hp.auction_first(32)

@@ -15,6 +15,7 @@ base = None
 for n in (1, 2, 4, 8):
     b = 32 // n
     pred, gt = P[:b].contiguous(), G[:b].contiguous()
+    best, table = hp.choose_schedule(pred, gt) or ("forced: " + hp.order, {})   # measured per batch size, as bench.py does
     for _ in range(5):
         hp.step_overlapped(pred, gt)
     torch.cuda.synchronize()
@@ -34,4 +35,5 @@ for n in (1, 2, 4, 8):
         if name != "start":
             seg[name] = seg.get(name, 0.0) + timers[i - 1][1].elapsed_time(ev) / 10
     print(f"N = {n}: {b:2d} clouds per GPU: {ms:.2f} ms per step -> speed-up {base / ms:.2f} of {n} ({base / ms / n:.0%})"
-          f"   one stream: " + " ".join(f"{k} {v:.2f}" for k, v in seg.items()) + f" = {sum(seg.values()):.2f} ms")
+          f"   one stream: " + " ".join(f"{k} {v:.2f}" for k, v in seg.items()) + f" = {sum(seg.values()):.2f} ms"
+          f"   schedule {best}: " + " ".join(f"{k} {v:.2f}" for k, v in table.items()))
