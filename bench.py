@@ -220,7 +220,7 @@ class HotPath:
         if self.one_stream(pred.size(0)):   # measured: no overlapped order beats the plain sequence at this batch size
             return self.step(pred, gt)
         if self.auction_first(pred.size(0)):
-            return self._step_auction_first(pred, gt, main)
+            return self._step_auction_first(pred, gt, main, strict=self.auction_strict(pred.size(0)))
         if self.side is None:
             self.side = torch.cuda.Stream()
         # tensors that cross streams are registered with the caching allocator: a block freed on its own stream
@@ -258,18 +258,24 @@ class HotPath:
         expansion | Chamfer -> auction with the renderer beside it stays (16 / 8 / 4 clouds: 3.18 / 1.96 / 1.54-1.65 ms
         against 3.16-3.45 / 2.01 / 1.78: the auction's teams leave XCDs idle there, and the chain's head overlaps the
         renderer)."""
-        if self.order in ("auction_first", "chain", "one_stream"):
-            return self.order == "auction_first"
+        if self.order in ("auction_first", "auction_strict", "chain", "one_stream"):
+            return self.order in ("auction_first", "auction_strict")
         if clouds in self.schedule:
-            return self.schedule[clouds][0] == "auction_first"
+            return self.schedule[clouds][0] in ("auction_first", "auction_strict")
         return clouds >= 24   # before / without choose_schedule(): round 4's table
+
+    def auction_strict(self, clouds):
+        """auction first AND nothing else before it is done (see _step_auction_first)."""
+        if self.order != "auto":
+            return self.order == "auction_strict"
+        return clouds in self.schedule and self.schedule[clouds][0] == "auction_strict"
 
     def one_stream(self, clouds):
         if self.order != "auto":
             return self.order == "one_stream"
         return clouds in self.schedule and self.schedule[clouds][0] == "one_stream"
 
-    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first")
+    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first", "auction_strict")
 
     def choose_schedule(self, pred, gt, reps=6, reduce_max=None):
         """Time every schedule on THIS batch during the untimed warm-up and keep the fastest (round 5 shipped a constant
@@ -300,7 +306,7 @@ class HotPath:
         self.schedule[clouds] = (best, table)
         return self.schedule[clouds]
 
-    def _step_auction_first(self, pred, gt, main):
+    def _step_auction_first(self, pred, gt, main, strict=False):
         """The auction on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two
         more streams.  The auction's launch duration measured LIVE includes its wait for the previous step's tail to
         leave the CUs (`roofline.isolated` is the kernel's own time)."""
@@ -314,6 +320,15 @@ class HotPath:
         with torch.cuda.stream(self.hi):
             loss_emd = self._loss_emd(pred, gt)
         loss_emd.record_stream(main)
+        if strict:
+            # Everything else starts only when the auction is DONE.  Without this the renderer's gather (VALU bound,
+            # 1.35 ms) and the expansion penalty's lone waves (one per SIMD for 0.5 ms) reach the compute units during
+            # the auction's ~0.1 ms of preparation kernels, and the persistent grid -- which needs every CU's whole
+            # register file -- spins until they have drained: its live window was 3.1 ms against 1.92 ms of execution
+            # (profiles/r04_c_bench.json).  The losers are the others' small prologue kernels, which no longer overlap
+            # the auction's preparation.
+            self.side.wait_stream(self.hi)
+            main.wait_stream(self.hi)
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
         acc.record_stream(main)
@@ -1123,7 +1138,8 @@ def main():
                 "streams": (1 if hp.one_stream(b_local) else
                             (3 if (hp.three_streams(b_local) or hp.auction_first(b_local)) else 2)) if overlap else 1,
                 "order": ("one stream" if hp.one_stream(b_local) else
-                          "auction first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_first(b_local)
+                          "auction alone first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_strict(b_local) else
+                          "auction first (high-priority stream), renderer | Chamfer + expansion beside and after it" if hp.auction_first(b_local)
                           else "expansion | Chamfer -> auction, renderer beside") if overlap else "one stream",
                 # the stream orders timed on this batch during the untimed warm-up (HotPath.choose_schedule): ms per step
                 "schedule_table_ms": (hp.schedule.get(b_local) or (None, None))[1],

@@ -161,6 +161,10 @@ __device__ __forceinline__ bool filter_pass(float s, float a_k, float cthr) {
 }
 
 // order-preserving float max through integer atomics
+// (Round 6 measured WORKGROUP-scope atomics for teams that sit on one XCD -- the running maxima, the list heads, the bin
+// counters and the barrier arrivals, on the argument that the team meets in that XCD's L2 exactly as its plain stores do:
+// bit-exact, verified by a third litmus part, and 2-3 % SLOWER on every kind of data (uniform 2.106 against 2.037 ms per
+// call at 32 clouds, untrained 31.6 against 30.8; profiles/r06_e_emd_atomics_scope_not_kept.txt).  Agent scope stays.)
 __device__ __forceinline__ void atomic_max_float(float *addr, float v) {
   if (v >= 0.f)
     __hip_atomic_fetch_max(reinterpret_cast<int *>(addr), __float_as_int(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -249,6 +249,13 @@ __global__ __launch_bounds__(64) void expansion_fwd_kernel(
   }
 }
 
+// (Round 6 built a TWO-WAVES-PER-PATCH form for the 4 / 8 / 16-cloud shares of a multi-GPU job -- 128 lanes own a patch,
+// half the per-round vector work per wave, one LDS exchange {key, count, vertex, x, y, z} + one workgroup barrier per
+// round, the square-root tie branch across the two waves: bit-identical on every test, and NOT faster: 0.335 against
+// 0.325 ms at 4 clouds, 0.372 against 0.360 at 32 (profiles/r06_d_expansion_two_waves_not_kept.txt).  A round is a
+// chain of ~150 DEPENDENT instructions of one wave (LDS read -> distances -> relaxation -> wave minimum -> ballots ->
+// readlane), 640 ns; halving the lanes' work shortens none of its links and the exchange adds one.  Removed.)
+
 // mean_mst_length[b] = sum over patches in ascending patch order (fixed order:
 // the reference's fp32 atomicAdd is order dependent)
 __global__ void expansion_mean_kernel(int B, int np, const float *__restrict__ patch_mean,

@@ -55,6 +55,10 @@ extern "C" int sn_mds_debug_stamps(unsigned long long *out8, int reset) {
 
 namespace {
 
+__device__ __forceinline__ float lane_f(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m, int width) {
   const unsigned lo = __shfl_xor((unsigned)v, m, width);
   const unsigned hi = __shfl_xor((unsigned)(v >> 32), m, width);
@@ -537,15 +541,20 @@ template <int PG>
 __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     int B, int n, int m, const float *__restrict__ xyz, const int *__restrict__ perm_all,
     const float *__restrict__ bbox, const float *__restrict__ mean_mst_length, int *__restrict__ idxs,
-    MdsTeamCtl *ctl, unsigned *sticky, int G, int teams, int xcd_local, unsigned spin_limit, float team_ratio) {
+    MdsTeamCtl *ctl, unsigned *sticky, int G, int teams, int xcd_local, unsigned spin_limit, float team_ratio, int nw) {
 #pragma clang fp contract(off)
-  extern __shared__ __attribute__((aligned(16))) float yz[];  // [PG*1024][2], lane private
+  extern __shared__ __attribute__((aligned(16))) float yz[];  // [PG * nthreads][2], lane private
   __shared__ int s_ticket;
   __shared__ unsigned wave_val[2][16];
+  __shared__ unsigned wave_sec[2][16];
   __shared__ float4 wave_pick[2][16];  // x, y, z, low bits
-  __shared__ float4 s_pick[2];         // the team's pick of the round: x, y, z, low bits
   __shared__ int s_state[2], s_stray;  // 1: a pick, 0: nothing below 1e9 anywhere, -1: a member never answered
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int nthreads = nw * 64;  // nw <= 16 waves per member (round 6: as many as its share of the cloud needs)
+  if (tid < 32) {  // hand-off entries of waves that do not exist stay neutral: never the minimum
+    wave_val[tid >> 4][tid & 15] = 0xffffffffu;
+    wave_sec[tid >> 4][tid & 15] = 0xffffffffu;
+  }
   if (tid == 0) {
     int t = -1;
     s_stray = 0;
@@ -594,13 +603,13 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
   float blx = 3e38f, bly = 3e38f, blz = 3e38f, bhx = -3e38f, bhy = -3e38f, bhz = -3e38f;
 #pragma unroll
   for (int i = 0; i < PG; ++i) {
-    const int s = (((g * PG + i) * 16 + wave) << 6) + lane;  // sorted position: slot g PG + i of the one-workgroup layout
+    const int s = (((g * PG + i) * nw + wave) << 6) + lane;  // sorted position: the member owns PG x nw consecutive groups of 64
     const bool valid = s < n;
     const int k = valid ? perm[s] : 0;
     const float x = p[k * 3 + 0], y = p[k * 3 + 1], z = p[k * 3 + 2];
     px[i] = valid ? x : 0.f;
-    yz[2 * (i * 1024 + tid) + 0] = valid ? y : 0.f;
-    yz[2 * (i * 1024 + tid) + 1] = valid ? z : 0.f;
+    yz[2 * (i * nthreads + tid) + 0] = valid ? y : 0.f;
+    yz[2 * (i * nthreads + tid) + 1] = valid ? z : 0.f;
     tmp[i] = valid ? 0.f : 1e9f;
     low[i] = valid ? ((__brev((unsigned)(k & 1023)) >> 22) << 16) | ((unsigned)k << 1) | (k >= 8192 ? 1u : 0u)
                    : 0xffffffffu;
@@ -659,35 +668,76 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     __syncthreads();
     if (s_state[0] < 0) {  // the team never formed: nothing of this cloud is a result (-1: sn_gather_* -> NaN)
       if (g == 0)
-        for (int e = tid; e < m; e += 1024) out[e] = -1;
+        for (int e = tid; e < m; e += nthreads) out[e] = -1;
       return;
     }
     loc = s_state[0] == 1;
     __syncthreads();
   }
 
+  // ---- rounds: SEVERAL PICKS PER EXCHANGE (round 6) ----------------------------------------------------------------
+  // A round of rounds 3-5 was: update -> arg-min in the workgroup -> exchange of one word per member -> the pick's
+  // coordinates: 1.7 us, of which 0.84 us exchange + coordinates (profiles/r06_a_mds_dense_stamps.txt).  Now an exchange
+  // carries, per member, its lowest candidate WITH its coordinates and its SECOND lowest density, and every member
+  // replays the same deterministic little auction among the G candidates:
+  //   pick 1 = the smallest key (density, tie key) of the G candidates -- the team's arg-min, as before;
+  //   after a pick, a candidate's new density needs only its old density and the pick's coordinates: the replay adds
+  //     exactly what the owner will add (same operands, same operations: bit-identical), the picked one goes to 1e9;
+  //   pick q + 1 = the smallest replayed key -- PROVIDED it is strictly below `bound`, the smallest of the members'
+  //     second-lowest densities at the time of the exchange: densities only grow, so every point that is not a
+  //     candidate still has a density >= its member's second-lowest >= bound, and the replayed minimum is the arg-min
+  //     of the whole cloud (an equal density outside the set could win on the tie key: strict '<' stops there).
+  // The accepted picks are then applied in pick order by every member (each density takes its increments in the
+  // reference's order: the per-round rounding of (float)((double)temp + w exp) is replayed exactly), and the next
+  // arg-min runs once per exchange.  On the dense regime's data the test accepts 2.5-4.6 picks per exchange
+  // (tools/sim/mds_dense_staleness.py: the lowest densities belong to points far from every pick so far, which a new pick
+  // far away hardly changes).  The index sequence is the reference's by construction; tests/test_mds.py and
+  // tests/test_fullsize.py compare it with the oracle's.
+  constexpr int kMaxQ = 8;  // picks per exchange at most
+  __shared__ float4 s_picks[kMaxQ];  // x, y, z, low bits
+  __shared__ int s_npick;
+  if (tid == 0) s_picks[0] = make_float4(x0, y0, z0, __uint_as_float(0u));  // the first sample: point 0 (idx[0] = 0)
+  __syncthreads();
+  (void)last;
 #ifdef SN_MDS_STAMPS
   const bool stamping = b == 0 && g == 0 && wave == 0;
   long long st_acc[6] = {0, 0, 0, 0, 0, 0};
   long long st_tk = (long long)__builtin_amdgcn_s_memrealtime();
+  unsigned st_ex = 0;
 #endif
-  for (int j = 1; j < m; ++j) {
-    const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
-    const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
-    const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
-    const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
-    unsigned mn = 0xffffffffu;
+  int j = 1, npick = 1;
+  for (unsigned ex = 1; j < m; ++ex) {
+    // the picks decided by the previous exchange (first: point 0), in pick order
+    for (int q = 0; q < npick; ++q) {  // uniform
+      const float4 pq = s_picks[q];
+      x1 = pq.x;
+      y1 = pq.y;
+      z1 = pq.z;
+      last_low = __float_as_uint(pq.w);
+      const float gx = __builtin_fmaxf(__builtin_fmaxf(blx - x1, x1 - bhx), 0.f);
+      const float gy = __builtin_fmaxf(__builtin_fmaxf(bly - y1, y1 - bhy), 0.f);
+      const float gz = __builtin_fmaxf(__builtin_fmaxf(blz - z1, z1 - bhz), 0.f);
+      const unsigned mask = (unsigned)__ballot((gx * gx + gy * gy) + gz * gz < far2);
+#pragma unroll
+      for (int i = 0; i < PG; ++i) {
+        if ((mask >> i) & 1u) {  // wave-uniform
+          const float v = (low[i] == last_low) ? 1e9f : tmp[i];
+          const float2 qq = reinterpret_cast<const float2 *>(yz)[i * nthreads + tid];
+          const float dx = px[i] - x1, dy = qq.x - y1, dz = qq.y - z1;
+          const float d = (dx * dx + dy * dy) + dz * dz;
+          const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
+          tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
+        }  // (the pick's own slot is always inside the ball: its 1e9 mark is never skipped)
+      }
+    }
+    MDS_STAMP(0)
+    // this lane's smallest and second smallest density (equal densities count), then the wave's
+    unsigned mn = 0xffffffffu, m2 = 0xffffffffu;
 #pragma unroll
     for (int i = 0; i < PG; ++i) {
-      if ((mask >> i) & 1u) {  // wave-uniform
-        const float v = (low[i] == last_low) ? 1e9f : tmp[i];
-        const float2 q = reinterpret_cast<const float2 *>(yz)[i * 1024 + tid];
-        const float dx = px[i] - x1, dy = q.x - y1, dz = q.y - z1;
-        const float d = (dx * dx + dy * dy) + dz * dz;
-        const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
-        tmp[i] = v + __builtin_ldexpf(e, (int)(low[i] & 1u));
-      }  // (the pick's own slot is always inside the ball: its 1e9 mark is never skipped)
-      mn = umin32(mn, __float_as_uint(tmp[i]));
+      const unsigned v = __float_as_uint(tmp[i]);
+      m2 = umin32(m2, v > mn ? v : mn);
+      mn = umin32(mn, v);
     }
     // arg-min of (density, low) inside the wave: the full key comparison (PG is small)
     const unsigned wm = wave_min_u32(mn);
@@ -703,76 +753,134 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     }
     const unsigned wlmin = wave_min_u32(wl);
     const bool winner = wl == wlmin && wl != 0xffffffffu;  // lows of real points are unique
-    const int buf = j & 1;
-    if (lane == 0) wave_val[buf][wave] = wm;
-    if (winner) {
-      const float2 q = reinterpret_cast<const float2 *>(yz)[wi * 1024 + tid];
-      wave_pick[buf][wave] = make_float4(wx, q.x, q.y, __uint_as_float(wl));
+    // the wave's second smallest density: the winner lane contributes its own second, every other lane its smallest
+    const unsigned wsec = wave_min_u32(winner ? m2 : mn);
+    const int buf = (int)(ex & 1u);
+    if (lane == 0) {
+      wave_val[buf][wave] = wm;
+      wave_sec[buf][wave] = wsec;
     }
-    MDS_STAMP(0)
+    if (winner) {
+      const float2 qq = reinterpret_cast<const float2 *>(yz)[wi * nthreads + tid];
+      wave_pick[buf][wave] = make_float4(wx, qq.x, qq.y, __uint_as_float(wl));
+    }
     __syncthreads();
     MDS_STAMP(1)
-    const int l16 = lane & 15;
-    const unsigned v16 = wave_val[buf][l16];
-    const float4 pk = wave_pick[buf][l16];
-    const unsigned minv = row_min_u32(v16);
-    const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
-    const unsigned minl = row_min_u32(lw);
-    // this workgroup's candidate: (minv, minl); "nothing below 1e9" travels as (>= kBig, all ones).
-    // (Round 5 let the candidate's COORDINATES ride with it -- four stamped 64-bit words per member and round instead of
-    // one, so that nobody reads the pick's coordinates from xyz afterwards: index-exact, and slower, 30.8 -> 32.1 ms at 32
-    // clouds, 27.2 -> 28.9 at 4: the uniform load of constant data that it saves is cheaper than four words per poll.)
     if (wave == 0) {  // ONE wave per workgroup talks to the others (sixteen pollers per workgroup on the same lines
                       // slowed every store down); the rest of the workgroup waits at the barrier below
+      const int l16 = lane & 15;
+      const unsigned v16 = wave_val[buf][l16], s16 = wave_sec[buf][l16];
+      const float4 pk = wave_pick[buf][l16];
+      const unsigned minv = row_min_u32(v16);
+      const unsigned lw = v16 == minv ? __float_as_uint(pk.w) : 0xffffffffu;
+      const unsigned minl = row_min_u32(lw);
+      const int wsel = (int)__builtin_ctzll(__ballot(lw == minl));  // < 16: the wave that holds the member's candidate
+      const unsigned msec = row_min_u32(l16 == wsel ? s16 : v16);   // the member's second smallest density
+      // this workgroup's candidate: (minv, minl) + coordinates; "nothing below 1e9" travels as (>= kBig, all ones)
       const unsigned my_val = (unsigned)__builtin_amdgcn_readfirstlane((int)minv);
       const unsigned my_low = my_val >= kBig ? 0x3ffffffu : ((unsigned)__builtin_amdgcn_readfirstlane((int)minl) & 0x3ffffffu);
-      const unsigned long long mine =
-          ((unsigned long long)my_val << 32) | ((unsigned long long)my_low << 6) | (unsigned long long)(j & 63);
+      const unsigned my_sec = (unsigned)__builtin_amdgcn_readfirstlane((int)msec);
+      const unsigned xb = (unsigned)__builtin_amdgcn_readlane(__float_as_int(pk.x), wsel);
+      const unsigned yb = (unsigned)__builtin_amdgcn_readlane(__float_as_int(pk.y), wsel);
+      const unsigned zb = (unsigned)__builtin_amdgcn_readlane(__float_as_int(pk.z), wsel);
+      const unsigned stamp = ex & 63u;
+      // four 64-bit words in the member's line, EACH with the exchange's stamp in its low six bits (a word is either
+      // entirely of this exchange or not: no fence, no flag + data pair):
+      //   W0 = density : 32 | low key : 26 | stamp     W1 = second density : 32 | x[31:6] : 26 | stamp
+      //   W2 = y : 32 | z[31:6] : 26 | stamp            W3 = x[5:0] << 12 | z[5:0] << 6 | stamp
       unsigned long long *slot = words + ((size_t)buf * G) * kWordStride;
-      if (lane == 0) {
+      if (lane < 4) {
+        const unsigned long long w0 = ((unsigned long long)my_val << 32) | ((unsigned long long)my_low << 6) | stamp;
+        const unsigned long long w1 = ((unsigned long long)my_sec << 32) | (unsigned long long)(xb & ~63u) | stamp;
+        const unsigned long long w2 = ((unsigned long long)yb << 32) | (unsigned long long)(zb & ~63u) | stamp;
+        const unsigned long long w3 = ((unsigned long long)(xb & 63u) << 12) | ((unsigned long long)(zb & 63u) << 6) | stamp;
+        const unsigned long long mine = lane == 0 ? w0 : (lane == 1 ? w1 : (lane == 2 ? w2 : w3));
         // a team on ONE XCD keeps its words in that XCD's L2 (plain store; the pollers' coherent loads meet it
         // there); an agent-scope store goes out to the fabric and takes the line with it
         if (loc)
-          __hip_atomic_store(&slot[(size_t)g * kWordStride], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          __hip_atomic_store(&slot[(size_t)g * kWordStride + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else
-          __hip_atomic_store(&slot[(size_t)g * kWordStride], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&slot[(size_t)g * kWordStride + lane], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      unsigned long long w = mine;
+      // lane l < G: member l's candidate
+      unsigned cv = my_val, cl = my_low, csec = my_sec;
+      float cx = __uint_as_float(xb), cy = __uint_as_float(yb), cz = __uint_as_float(zb);
+      bool stale = false;
       if (lane < G && lane != g) {
+        const unsigned long long *src = &slot[(size_t)lane * kWordStride];
+        unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
         unsigned spins = 0;
         for (;;) {
-          w = __hip_atomic_load(&slot[(size_t)lane * kWordStride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if ((unsigned)(w & 63ull) == (unsigned)(j & 63)) break;
+          w0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w3 = __hip_atomic_load(src + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((((unsigned)w0 ^ stamp) | ((unsigned)w1 ^ stamp) | ((unsigned)w2 ^ stamp) | ((unsigned)w3 ^ stamp)) << 26 == 0u) break;
           __builtin_amdgcn_s_sleep(1);
           if ((++spins & 1023u) == 0u) {
-            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+            if (__hip_atomic_load(&ctl->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { stale = true; break; }
             if (spins > spin_limit) {
               __hip_atomic_store(&ctl->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+              stale = true;
               break;
             }
           }
         }
+        cv = (unsigned)(w0 >> 32);
+        cl = (unsigned)(w0 >> 6) & 0x3ffffffu;
+        csec = (unsigned)(w1 >> 32);
+        cx = __uint_as_float(((unsigned)w1 & ~63u) | ((unsigned)(w3 >> 12) & 63u));
+        cy = __uint_as_float((unsigned)(w2 >> 32));
+        cz = __uint_as_float(((unsigned)w2 & ~63u) | ((unsigned)(w3 >> 6) & 63u));
       }
       MDS_STAMP(2)
-      const bool stale = lane < G && (unsigned)(w & 63ull) != (unsigned)(j & 63);
-      unsigned long long key = lane < G ? (w >> 6) : ~0ull;
-#pragma unroll
-      for (int sft = 1; sft < 16; sft <<= 1) {  // G <= 16
-        const unsigned long long o = shfl_xor_u64(key, sft, 16);
-        key = o < key ? o : key;
+      if (lane >= G) {
+        cv = 0xffffffffu;
+        cl = 0x3ffffffu;
+        csec = 0xffffffffu;
       }
-      const unsigned khi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(key >> 32));
-      const unsigned klo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)key);
-      const unsigned long long kmin = ((unsigned long long)khi << 32) | klo;
-      const unsigned val = (unsigned)(kmin >> 26);
-      const unsigned lw2 = (unsigned)(kmin & 0x3ffffffull);
-      const int k = val >= kBig ? 0 : (int)((lw2 >> 1) & 0x7fffu);
-      const float px_ = p[k * 3 + 0], py_ = p[k * 3 + 1], pz_ = p[k * 3 + 2];  // uniform address, constant data
-      const bool any_stale = __any(stale);  // voted by the whole wave, not inside the one-lane branch below
+      const bool any_stale = __any(stale);  // voted by the whole wave, not inside a one-lane branch
+      // what no member published: every such point's density is >= its member's second smallest >= bound
+      const unsigned bound = wave_min_u32(csec);
+      // (Measured and not kept, round 6: the G x G increments the candidates would receive from each other computed
+      // up front by the wave's 64 lanes -- four independent evaluations per lane -- and the replay reduced to a
+      // minimum, an LDS row read and an add per pick: 481 ns of replay per pick against 418 with the chain below,
+      // profiles/r06_e_mds_dense_stamps_pair_matrix_not_kept.txt.)
+      int np = 0, state = 1;
+      const int room = m - j;  // picks still wanted (>= 1)
+      for (int q = 0; q < kMaxQ; ++q) {  // uniform
+        const unsigned mv = wave_min_u32(cv);
+        if (mv >= kBig) {  // nothing below 1e9 anywhere: the reference's threads all report (1e9, index 0)
+          if (q == 0) {
+            if (lane == 0) s_picks[0] = make_float4(x0, y0, z0, __uint_as_float(0u));
+            np = 1;
+            state = 0;
+          }
+          break;
+        }
+        if (q > 0 && !(mv < bound)) break;  // a point outside the candidate set could be the arg-min
+        unsigned long long eq = __ballot(cv == mv);
+        if (__popcll(eq) > 1) {  // equal densities: the smaller tie key wins
+          const unsigned ml = wave_min_u32(cv == mv ? cl : 0xffffffffu);
+          eq = __ballot(cv == mv && cl == ml);
+        }
+        const int wq = (int)__builtin_ctzll(eq);
+        const float qx = lane_f(cx, wq), qy = lane_f(cy, wq), qz = lane_f(cz, wq);
+        const unsigned ql = (unsigned)__builtin_amdgcn_readlane((int)cl, wq);
+        if (lane == 0) s_picks[q] = make_float4(qx, qy, qz, __uint_as_float(ql));
+        np = q + 1;
+        if (np >= room) break;
+        // the candidates after this pick: exactly the owner's update (same operands, same operations)
+        const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
+        const float d = (dx * dx + dy * dy) + dz * dz;
+        const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
+        const float nv = __uint_as_float(cv) + __builtin_ldexpf(e, (int)(cl & 1u));
+        cv = lane >= G ? 0xffffffffu : (lane == wq ? kBig : __float_as_uint(nv));
+      }
       if (lane == 0) {
-        s_pick[buf] = make_float4(px_, py_, pz_, __uint_as_float(val >= kBig ? 0u : lw2));
-        s_state[buf] = any_stale ? -1 : (val >= kBig ? 0 : 1);
+        s_npick = np;
+        s_state[buf] = any_stale ? -1 : state;
       }
 #ifdef SN_MDS_STAMPS
       if (stamping) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -781,26 +889,27 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
     }
     __syncthreads();
     MDS_STAMP(4)
+#ifdef SN_MDS_STAMPS
+    ++st_ex;
+#endif
     const int state = s_state[buf];
     if (state < 0) {  // a member never answered (workgroup-uniform): the WHOLE row becomes -1 -- a partial sequence
       if (g == 0)     // would look like a result; sn_gather_forward turns -1 into NaN, the next sn_mds call fails
-        for (int e = tid; e < m; e += 1024) out[e] = -1;
+        for (int e = tid; e < m; e += nthreads) out[e] = -1;
       return;
     }
-    {
-      const float4 pk2 = s_pick[buf];
-      last_low = __float_as_uint(pk2.w);
-      last = state ? (int)((last_low >> 1) & 0x7fffu) : 0;  // state 0: nothing below 1e9 anywhere -> (1e9, index 0)
-      x1 = pk2.x;
-      y1 = pk2.y;
-      z1 = pk2.z;
+    npick = s_npick;
+    if (tid < npick && g == 0) {  // state 0: nothing below 1e9 anywhere -> (1e9, index 0)
+      const unsigned lwq = __float_as_uint(s_picks[tid].w);
+      out[j + tid] = state ? (int)((lwq >> 1) & 0x7fffu) : 0;
     }
-    if (tid == 0 && g == 0) out[j] = last;
+    j += npick;
   }
 #ifdef SN_MDS_STAMPS
   if (stamping && lane == 0) {
     for (int i = 0; i < 5; ++i) atomicAdd(&g_mds_stamps[i], (unsigned long long)st_acc[i]);
     atomicAdd(&g_mds_stamps[5], (unsigned long long)(m - 1));
+    atomicAdd(&g_mds_stamps[6], (unsigned long long)st_ex);
   }
 #endif
 }
@@ -963,31 +1072,38 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
       SN_HIP(hipGetDevice(&dev));
       if (const int rc = sn::check_sticky(dev, "sn_mds")) return rc;
       SN_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-      static const int gmax = [] { const char *e = getenv("SN_MDS_G"); const int v = e ? atoi(e) : 16; return v >= 1 && v <= 16 ? v : 16; }();
+      static const int gmax = [] { const char *e = getenv("SN_MDS_G"); const int v = e ? atoi(e) : 32; return v >= 1 && v <= 32 ? v : 32; }();
+      // A member owns PG x nw consecutive groups of 64 sorted points (nw <= 16 waves, PG register slots per lane): the
+      // cloud's ceil(n / 64) groups are dealt out evenly.  (Rounds 3-5 dealt out whole slots of 1024 points: at n = 19384
+      // and G = 16 ten members held two slots each and six held nothing.)  G = the largest power of two <= 32 such that
+      // every cloud's team fits one XCD's share of the compute units and a member still has four waves of points.
+      const int groups = (n + 63) / 64;
       if (cus >= 64 && cus % 8 == 0 && ppt >= 2) {
         const int per = cus / 8, tpx = (b + 7) / 8;
         int g = 1;
-        while (g * 2 * tpx <= per && g * 2 <= gmax && g * 2 <= ppt) g *= 2;
+        while (g * 2 * tpx <= per && g * 2 <= gmax && g * 2 * 4 <= groups) g *= 2;
         team_g = g;
         team_slots = 8 * tpx;
       }
       if (team_g >= 2 && sn::capturing(s)) team_g = 1;  // under graph capture: the one-workgroup kernel only
       if (team_g >= 2) {
-        const int pg = (ppt + team_g - 1) / team_g;
+        const int per_member = (groups + team_g - 1) / team_g;        // groups of 64 points a member owns
+        const int pg = (per_member + 15) / 16;                        // register slots per lane
+        const int nw = (per_member + pg - 1) / pg;                    // waves per member (<= 16)
         unsigned *sticky = sn::sticky_device_word(dev);
         // SN_MDS_DIAG=8 (tests): the second member of cloud 0's team leaves at once and the polls give up early
         const char *dg = SN_KNOB("SN_MDS_DIAG");
         const bool park = dg && atoi(dg) == 8;
-        SN_REQUIRE(team_slots * team_g <= 1024, "sn_mds: unexpected team geometry");
+        SN_REQUIRE(team_slots * team_g <= 1024 && pg <= 10, "sn_mds: unexpected team geometry");
         SN_HIP(hipMemsetAsync(tctl, 0, 128 + 128 * 3 * (size_t)team_slots * team_g, s));
         sn::PersistentLaunch chain(dev, s);  // never beside another team-waiting launch of this process (common.hpp)
 #define SN_MDST(P)                                                                                          \
   {                                                                                                         \
     SN_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&mds_dense_team_kernel<P>),                   \
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));             \
-    mds_dense_team_kernel<P><<<team_slots * team_g, 1024, (size_t)P * 8192, s>>>(                           \
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));             \
+    mds_dense_team_kernel<P><<<team_slots * team_g, nw * 64, (size_t)P * nw * 64 * 8, s>>>(                 \
         b, n, m, xyz, perm, bbox, mean_mst_length, idx, tctl, sticky, team_g, team_slots, park ? 3 : 1,     \
-        park ? 1u << 14 : 1u << 24, team_ratio);                                                            \
+        park ? 1u << 14 : 1u << 24, team_ratio, nw);                                                        \
   }
         if (pg <= 1) SN_MDST(1)
         else if (pg <= 2) SN_MDST(2)

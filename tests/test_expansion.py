@@ -155,3 +155,4 @@ def test_hip_full_size(dev):
     assert ((a < 0) == (d == 0)).all()
     pen = a >= 0
     assert (a[pen] // 512 == np.nonzero(pen)[1] // 512).all()
+

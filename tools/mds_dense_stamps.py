@@ -12,8 +12,8 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(7)
 x = torch.rand(32, 19384, 3, generator=g).to(dev)
 lib = sparenet_amd.lib()
-names = ["update + arg-min in the wave", "barrier 1 (slowest wave)", "store + poll of the team's words",
-         "minimum + pick's coordinates", "barrier 2 + hand-over"]
+names = ["updates of the accepted picks", "arg-min + second density + barrier A", "store + poll of the team's words",
+         "replay among the candidates", "barrier B + hand-over"]
 for b in (32, 4):
     for mm in (0.0853, 0.05):
         mml = torch.full((b,), mm, device=dev)
@@ -24,7 +24,7 @@ for b in (32, 4):
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(); minimum_density_sample(xs, 16384, mml); e.record(); torch.cuda.synchronize()
         lib.sn_mds_debug_stamps(out, 1)
-        rounds = max(1, out[5])
-        per = [out[i] * 10.0 / rounds for i in range(5)]   # ns per round (100 MHz ticks)
-        print(f"mds dense B={b} mml={mm}: {a.elapsed_time(e):.2f} ms per call (stamps build), {rounds} rounds, "
-              f"{sum(per):.0f} ns per round = " + ", ".join(f"{n} {p:.0f}" for n, p in zip(names, per)), flush=True)
+        rounds, exch = max(1, out[5]), max(1, out[6])
+        per = [out[i] * 10.0 / rounds for i in range(5)]   # ns per PICK (100 MHz ticks)
+        print(f"mds dense B={b} mml={mm}: {a.elapsed_time(e):.2f} ms per call (stamps build), {rounds} picks in {exch} exchanges "
+              f"({rounds / exch:.2f} picks per exchange), {sum(per):.0f} ns per pick = " + ", ".join(f"{n} {p:.0f}" for n, p in zip(names, per)), flush=True)
