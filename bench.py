@@ -166,7 +166,7 @@ class HotPath:
         self.side = None
         self.side2 = None
         self.hi = None
-        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first" / "chain" / "one_stream" force an order (A/B); auto: MEASURED
+        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first[_cd_exp|_main_after]" / "chain" / "one_stream" force an order (A/B); auto: MEASURED
         self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: measured with the order
         # batch size -> (schedule name, {schedule: ms}) chosen by choose_schedule() during the untimed warm-up
         self.schedule = {}
@@ -220,7 +220,7 @@ class HotPath:
         if self.one_stream(pred.size(0)):   # measured: no overlapped order beats the plain sequence at this batch size
             return self.step(pred, gt)
         if self.auction_first(pred.size(0)):
-            return self._step_auction_first(pred, gt, main, strict=self.auction_strict(pred.size(0)))
+            return self._step_auction_first(pred, gt, main)
         if self.side is None:
             self.side = torch.cuda.Stream()
         # tensors that cross streams are registered with the caching allocator: a block freed on its own stream
@@ -258,24 +258,18 @@ class HotPath:
         expansion | Chamfer -> auction with the renderer beside it stays (16 / 8 / 4 clouds: 3.18 / 1.96 / 1.54-1.65 ms
         against 3.16-3.45 / 2.01 / 1.78: the auction's teams leave XCDs idle there, and the chain's head overlaps the
         renderer)."""
-        if self.order in ("auction_first", "auction_strict", "chain", "one_stream"):
-            return self.order in ("auction_first", "auction_strict")
-        if clouds in self.schedule:
-            return self.schedule[clouds][0] in ("auction_first", "auction_strict")
-        return clouds >= 24   # before / without choose_schedule(): round 4's table
-
-    def auction_strict(self, clouds):
-        """auction first AND nothing else before it is done (see _step_auction_first)."""
         if self.order != "auto":
-            return self.order == "auction_strict"
-        return clouds in self.schedule and self.schedule[clouds][0] == "auction_strict"
+            return self.order.startswith("auction_first")
+        if clouds in self.schedule:
+            return self.schedule[clouds][0].startswith("auction_first")
+        return clouds >= 24   # before / without choose_schedule(): round 4's table
 
     def one_stream(self, clouds):
         if self.order != "auto":
             return self.order == "one_stream"
         return clouds in self.schedule and self.schedule[clouds][0] == "one_stream"
 
-    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first", "auction_strict")
+    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first", "auction_first_cd_exp", "auction_first_main_after")
 
     def choose_schedule(self, pred, gt, reps=6, reduce_max=None):
         """Time every schedule on THIS batch during the untimed warm-up and keep the fastest (round 5 shipped a constant
@@ -306,7 +300,7 @@ class HotPath:
         self.schedule[clouds] = (best, table)
         return self.schedule[clouds]
 
-    def _step_auction_first(self, pred, gt, main, strict=False):
+    def _step_auction_first(self, pred, gt, main):
         """The auction on a HIGH-PRIORITY stream, enqueued first; the renderer and Chamfer + expansion penalty on two
         more streams.  The auction's launch duration measured LIVE includes its wait for the previous step's tail to
         leave the CUs (`roofline.isolated` is the kernel's own time)."""
@@ -320,20 +314,23 @@ class HotPath:
         with torch.cuda.stream(self.hi):
             loss_emd = self._loss_emd(pred, gt)
         loss_emd.record_stream(main)
-        if strict:
-            # Everything else starts only when the auction is DONE.  Without this the renderer's gather (VALU bound,
-            # 1.35 ms) and the expansion penalty's lone waves (one per SIMD for 0.5 ms) reach the compute units during
-            # the auction's ~0.1 ms of preparation kernels, and the persistent grid -- which needs every CU's whole
-            # register file -- spins until they have drained: its live window was 3.1 ms against 1.92 ms of execution
-            # (profiles/r04_c_bench.json).  The losers are the others' small prologue kernels, which no longer overlap
-            # the auction's preparation.
-            self.side.wait_stream(self.hi)
+        # (Round 6 measured "nothing else before the auction is DONE" -- the other streams wait for the high-priority
+        # stream -- on the theory that the gather and the expansion penalty's lone waves reach the compute units during
+        # the auction's preparation kernels and make the persistent grid wait for them: 4.59 ms against 4.32 at 32
+        # clouds, slower at every share (profiles/r06_g_strong_share.txt); what overlaps the auction's preparation and
+        # tail is worth more than the clean start.  Not kept.)
+        variant = self.schedule.get(pred.size(0), ("auction_first", None))[0] if self.order == "auto" else self.order
+        if variant == "auction_first_main_after":   # Chamfer + expansion penalty only once the auction is done
             main.wait_stream(self.hi)
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
         acc.record_stream(main)
-        loss_exp = self._loss_expansion(pred)
-        loss_cd = self._loss_cd(pred, gt)
+        if variant == "auction_first_cd_exp":       # the expansion penalty's 0.5 ms of lone waves last instead of first
+            loss_cd = self._loss_cd(pred, gt)
+            loss_exp = self._loss_expansion(pred)
+        else:
+            loss_exp = self._loss_expansion(pred)
+            loss_cd = self._loss_cd(pred, gt)
         main.wait_stream(self.hi)
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
@@ -1138,7 +1135,6 @@ def main():
                 "streams": (1 if hp.one_stream(b_local) else
                             (3 if (hp.three_streams(b_local) or hp.auction_first(b_local)) else 2)) if overlap else 1,
                 "order": ("one stream" if hp.one_stream(b_local) else
-                          "auction alone first (high-priority stream), then renderer | Chamfer + expansion" if hp.auction_strict(b_local) else
                           "auction first (high-priority stream), renderer | Chamfer + expansion beside and after it" if hp.auction_first(b_local)
                           else "expansion | Chamfer -> auction, renderer beside") if overlap else "one stream",
                 # the stream orders timed on this batch during the untimed warm-up (HotPath.choose_schedule): ms per step

@@ -693,7 +693,7 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
   // (tools/sim/mds_dense_staleness.py: the lowest densities belong to points far from every pick so far, which a new pick
   // far away hardly changes).  The index sequence is the reference's by construction; tests/test_mds.py and
   // tests/test_fullsize.py compare it with the oracle's.
-  constexpr int kMaxQ = 8;  // picks per exchange at most
+  constexpr int kMaxQ = 16;  // picks per exchange at most
   __shared__ float4 s_picks[kMaxQ];  // x, y, z, low bits
   __shared__ int s_npick;
   if (tid == 0) s_picks[0] = make_float4(x0, y0, z0, __uint_as_float(0u));  // the first sample: point 0 (idx[0] = 0)
@@ -871,7 +871,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
         if (lane == 0) s_picks[q] = make_float4(qx, qy, qz, __uint_as_float(ql));
         np = q + 1;
         if (np >= room) break;
-        // the candidates after this pick: exactly the owner's update (same operands, same operations)
+        // the candidates after this pick: exactly the owner's update (same operands, same operations).
+        // (Measured and not kept: skipping the exponential's chain when no candidate lies inside the pick's cut ball --
+        // the rule on surface clouds: -3 % there, +3 % in the dense regime, profiles/r06_i_mds_*.)
         const float dx = cx - qx, dy = cy - qy, dz = cz - qz;
         const float d = (dx * dx + dy * dy) + dz * dz;
         const float e = sn_expf_nonpositive(neg_div(d, t, rt, fast_div));
@@ -1058,6 +1060,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     // (G = 16) whatever the regime, the one-workgroup kernel 1.1 us (surface) ... 4.3 us (cut ball = the cloud);
     // the two cross where the cut ball's squared radius is ~0.15 of the box diagonal's.
     int team_g = 1, team_slots = 0;
+    float team_ratio_eff = 0.f;   // = team_ratio, or ~0 where teams serve every regime (set below)
     // a cloud goes to a team when its cut ball's squared radius exceeds this fraction of the squared diagonal of
     // its bounding box (SN_MDS_RATIO; measured cross-over)
     // (0.12 in rounds 3-4, from uniform cubes at chosen mean MST lengths.  The first sampler call of an UNTRAINED generator
@@ -1067,6 +1070,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
     // off on one workgroup (23.5 ms against 26-28 on a team), a trained generator's clouds are far below either.
     // profiles/r05_g_mds_team_ratio.txt)
     static const float team_ratio = [] { const char *e = getenv("SN_MDS_RATIO"); const float v = e ? (float)atof(e) : 0.075f; return v > 0.f ? v : 0.075f; }();
+    team_ratio_eff = team_ratio;
     {
       int dev = 0, cus = 0;
       SN_HIP(hipGetDevice(&dev));
@@ -1086,6 +1090,11 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
         team_slots = 8 * tpx;
       }
       if (team_g >= 2 && sn::capturing(s)) team_g = 1;  // under graph capture: the one-workgroup kernel only
+      // Round 6: with several picks per exchange a team of >= 8 members beats the one-workgroup kernel in EVERY regime of
+      // a SpareNet-sized cloud -- surface regime (mml 0.0085, 19384 -> 16384) 17.7 -> 10.6 ms at <= 8 clouds, 17.9 ->
+      // 15.4 at 32; surface-like clouds 18.0-23.5 -> 10.6-12.2 (profiles/r06_h_mds_team_everywhere.txt) -- so such
+      // clouds all go to teams; smaller clouds and teams keep the measured cross-over above.
+      if (team_g >= 8 && n >= 8192 && !getenv("SN_MDS_RATIO")) team_ratio_eff = 1e-30f;
       if (team_g >= 2) {
         const int per_member = (groups + team_g - 1) / team_g;        // groups of 64 points a member owns
         const int pg = (per_member + 15) / 16;                        // register slots per lane
@@ -1103,7 +1112,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));             \
     mds_dense_team_kernel<P><<<team_slots * team_g, nw * 64, (size_t)P * nw * 64 * 8, s>>>(                 \
         b, n, m, xyz, perm, bbox, mean_mst_length, idx, tctl, sticky, team_g, team_slots, park ? 3 : 1,     \
-        park ? 1u << 14 : 1u << 24, team_ratio, nw);                                                        \
+        park ? 1u << 14 : 1u << 24, team_ratio_eff, nw);                                                    \
   }
         if (pg <= 1) SN_MDST(1)
         else if (pg <= 2) SN_MDST(2)
@@ -1116,7 +1125,7 @@ extern "C" int sn_mds(const float *xyz, int b, int n, int m, const float *mean_m
 #undef SN_MDST
       }
     }
-    const float skip_ratio = team_g >= 2 ? team_ratio : 0.f;
+    const float skip_ratio = team_g >= 2 ? team_ratio_eff : 0.f;
     const size_t lds = (size_t)ppt * 1024 * 8;
 #define SN_MDSC(P)                                                                               \
   {                                                                                              \

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
   const float tx0 = (float)(cx * kCell), tx1 = tx0 + (kCell - 1), ty0 = (float)(cy * kCell),
               ty1 = ty0 + (kCell - 1);
   float tile_min[NR];  // wave-uniform: smallest b1 over the tile's pixels
-  GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_pairs = 0, dg_upd = 0, dg_amb = 0, dg_walk = 0;)
+  GDIAG(int dg_batches = 0, dg_cand = 0, dg_surv = 0, dg_pairs = 0, dg_upd = 0, dg_amb = 0, dg_walk = 0, dg_rings = 0;)
   bool dirty[NR];  // wave-uniform: some pixel's top three of radius k changed since tile_min[k] was taken
   auto refresh_tile_min = [&]() {
 #pragma unroll
@@ -575,11 +575,70 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     return beg < end;
   };
 
-  for (int step = 0; step <= 2 * ra.halo; ++step) {
+  // The same cells RING by ring (round 6): ring r = the cells max(|dxc|, |dyc|) = r away -- its top and bottom rows
+  // as runs, the two side cells of every row in between.  Every point of ring r >= 2 lies at least (r - 1) kCell
+  // pixels from every pixel of the tile, so ONE uniform test per ring and radius -- the largest feature of the call
+  // times the weight at that distance against the smallest running best of the tile -- says whether any candidate of
+  // the ring (and of every ring beyond it: farther, and the running bests only rise) can still come within the band
+  // of some pixel's best.  It is the per-candidate cull's own test with the ring's bounds in place of the candidate's,
+  // so what it skips the cull would have dropped one batch of 64 at a time: on the benchmark's clouds ring 2 holds
+  // 12 of the 21 cells of a tile at R = 10 (57 % of the candidates, 0.095 of the weight at best) and is skipped for
+  // nearly every tile.
+  auto ring_range = [&](int ring, int rstep, int part, int &beg, int &end) -> bool {
+    const int dyc = (rstep + 1) >> 1;  // row distance in cells (<= ring)
+    const int cyy = cy + ((rstep & 1) ? -dyc : dyc);
+    if (cyy < 0 || cyy >= cells_y) return false;
+    const float gy = (float)((dyc > 1 ? dyc - 1 : 0) * kCell);
+    const float rem = ra.s_max_all * 1.0001f - gy * gy;
+    if (rem < 0.f) return false;
+    int p_lo, p_hi;
+    if (dyc == ring) {  // the ring's top / bottom row (ring 0: the own cell): one run of cells
+      // (Measured and not kept: the 3 x 3 block as three runs of three cells -- fuller batches for the cull, 3.9 instead
+      // of 5.3 per tile -- lets the neighbours arrive before the own cell has raised the tile's bests: 51 survivors per
+      // tile instead of 35, gather 1.27 -> 1.50 ms, profiles/r06_i_render_kernels_3x3_runs_not_kept.txt.)
+      if (part != 0) return false;
+      int reach = (int)(__builtin_sqrtf(rem) * (1.0f / kCell)) + 1;
+      reach = reach < ring ? reach : ring;
+      p_lo = cx - reach > 0 ? cx - reach : 0;
+      p_hi = cx + reach < cells_x - 1 ? cx + reach : cells_x - 1;
+    } else {  // an inner row: the ring's left (part 0) and right (part 1) cell
+      const float gx = (float)((ring - 1) * kCell);
+      if (gx * gx > rem) return false;  // the corner cells the largest radius cannot reach
+      p_lo = p_hi = part == 0 ? cx - ring : cx + ring;
+      if (p_lo < 0 || p_lo >= cells_x) return false;
+    }
+    const int first_cell = cell_base + cyy * cells_x + p_lo;
+    beg = first_cell > 0 ? offs[first_cell - 1] : 0;
+    end = offs[cell_base + cyy * cells_x + p_hi];
+    return beg < end;
+  };
+  const float fmaxv = __uint_as_float(*fmax_bits);
+#ifndef SN_P2I_NO_RINGS
+  for (int ring = 0; ring <= ra.halo; ++ring) {
+    if (ring >= 2) {  // can anything of this ring still matter?  (uniform values: one answer for the wave)
+      const float g = (float)((ring - 1) * kCell);
+      const float g2 = g * g * 0.99999f;
+      bool live = false;
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const float ub = fmaxv * weight32_plus(__builtin_fminf(g2 * ra.inv_r2[k], 1.0f), 4e-6f);
+        live = live || (g2 <= ra.s_max[k] && tile_min[k] <= ub + band);
+      }
+      GDIAG(dg_rings += live ? 0 : 1;)
+      if (!live) break;
+    }
+   for (int rstep = 0; rstep <= 2 * ring; ++rstep) {
+    for (int part = 0; part < 2; ++part) {
+      int beg, end;
+      if (!ring_range(ring, rstep, part, beg, end)) continue;  // wave-uniform
+#else
+  {
+   for (int step = 0; step <= 2 * ra.halo; ++step) {
     const int nparts = step == 0 ? 3 : 1;
     for (int part = 0; part < nparts; ++part) {
       int beg, end;
       if (!row_range(step, part, beg, end)) continue;  // wave-uniform
+#endif
       float4 rec_next = make_float4(0.f, 0.f, 0.f, 0.f);
       if (beg + lane < end) rec_next = srec[beg + lane];
       for (int base = beg; base < end; base += 64) {
@@ -651,6 +710,9 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
               // Equal values keep their order of arrival, exactly like the compare chain of the other branch.
               // (inline assembly: hipcc puts a canonicalising v_max(x, x) in front of every fmaxf / fminf on a
               // loop-carried value; a, b1..b3 are finite -- products of finite numbers -- never NaN)
+              // (Round 6 measured a TWO-value ladder -- 8 instructions instead of 13, every pixel with a runner-up inside
+              // the band settled by the exact walk instead of two exact evaluations: 0.022 pixel slots per tile walk, and
+              // the gather goes from 1.27 to 1.30 ms: profiles/r06_j_render_kernels_two_value_ladder_not_kept.txt.)
               float ae, t, t2, n1, n2, n3;
               unsigned long long first, second;  // lane masks of ae > b1, ae > b2
               unsigned posv = pos, e2, nj1, nj2;
@@ -678,6 +740,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
         refresh_tile_min();
       }
     }
+   }
   }
 
   // ---- exact values: the winner, the runner-up when it is inside the band, an exact walk when the third is too
@@ -749,7 +812,7 @@ __global__ __launch_bounds__(256, 6) void p2i_gather_max_kernel(
     atomicAdd(&g_gather_diag[0], 1ull); atomicAdd(&g_gather_diag[1], (unsigned long long)dg_batches);
     atomicAdd(&g_gather_diag[2], (unsigned long long)dg_cand); atomicAdd(&g_gather_diag[3], (unsigned long long)dg_surv);
     atomicAdd(&g_gather_diag[4], (unsigned long long)dg_pairs); atomicAdd(&g_gather_diag[5], (unsigned long long)dg_upd);
-    atomicAdd(&g_gather_diag[6], (unsigned long long)dg_amb); atomicAdd(&g_gather_diag[7], (unsigned long long)dg_walk);
+    atomicAdd(&g_gather_diag[6], (unsigned long long)dg_amb); atomicAdd(&g_gather_diag[7], (unsigned long long)dg_walk + ((unsigned long long)dg_rings << 32));  // rings skipped: high half
   })
 }
 

@@ -158,7 +158,3 @@ def test_bench_step_schedule_by_batch():
     assert not hp.auction_first(32) and not hp.one_stream(16)
     hp.order = "one_stream"
     assert hp.one_stream(32) and not hp.auction_first(32)
-    hp.order, hp.schedule = "auto", {32: ("auction_strict", {})}
-    assert hp.auction_first(32) and hp.auction_strict(32) and not hp.one_stream(32) and not hp.three_streams(32)
-    hp.order = "auction_first"
-    assert hp.auction_first(32) and not hp.auction_strict(32)

@@ -18,7 +18,8 @@ for radii in ([5.0, 7.0, 10.0], [10.0], [5.0]):
     cdm(data, view_id=0, radius_list=radii); torch.cuda.synchronize()
     lib.sn_p2i_gather_diag(out, 1)
     w, b, c, s, pairs, upd, amb, walk = [int(v) for v in out]
+    rings, walk = walk >> 32, walk & 0xffffffff   # tiles that stopped at a ring boundary (round 6's ring-level test)
     print(f"radii {radii}: per 8x8 tile: batches {b / w:.1f}, candidates {c / w:.0f}, survive the cull {s / w:.1f}; "
           f"in-range (pixel, radius, candidate) pairs valued with the fp32 series {pairs / w:.0f}, of which inside the band "
           f"of the running best {upd / w:.0f}; pixel slots settled by winner + runner-up {amb / w:.3f}, by the exact walk "
-          f"{walk / w:.5f} (of {64 * len(radii)} slots)")
+          f"{walk / w:.5f} (of {64 * len(radii)} slots); tiles whose outer ring was skipped {rings / w:.3f}")
