@@ -846,7 +846,9 @@ __global__ __launch_bounds__(1024) void mds_dense_team_kernel(
       // (Measured and not kept, round 6: the G x G increments the candidates would receive from each other computed
       // up front by the wave's 64 lanes -- four independent evaluations per lane -- and the replay reduced to a
       // minimum, an LDS row read and an add per pick: 481 ns of replay per pick against 418 with the chain below,
-      // profiles/r06_e_mds_dense_stamps_pair_matrix_not_kept.txt.)
+      // profiles/r06_e_mds_dense_stamps_pair_matrix_not_kept.txt.  The same matrix spread over ALL the workgroup's waves
+      // between two more workgroup barriers: 15.1 against 13.8 ms per call at 4 clouds, 11.1 against 10.6 in the surface
+      // regime, profiles/r06_k_mds_pairs_all_waves_not_kept.txt.  The chain below stays.)
       int np = 0, state = 1;
       const int room = m - j;  // picks still wanted (>= 1)
       for (int q = 0; q < kMaxQ; ++q) {  // uniform
