@@ -1839,7 +1839,11 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         const float price_floor = a.eps < 0.f ? a.eps * (float)it : 0.f;
         c.a_max = filter_target(price_floor) + 9.5367431640625e-07f;
 #ifdef SN_BID_STAMPS
-        c.stamps = (a.diag && team == 0 && m < 3 && it >= 10) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
+#ifndef SN_STAMP_FROM   // experiment builds: the iterations whose bid phase is stamped (default: the tail, 10 .. iters - 1)
+#define SN_STAMP_FROM 10
+#define SN_STAMP_TO 1000000
+#endif
+        c.stamps = (a.diag && team == 0 && m < 3 && it >= SN_STAMP_FROM && it <= SN_STAMP_TO) ? a.dwords + 16 + 3200 + (m * 16 + wave) * 16 : nullptr;
 #endif
         // A CONTESTED auction (the team's `cont` word, read at the top: the same answer in every workgroup) or a
         // prediction that lies OFF the targets (`far`, from the seed kernel): hundreds of far bidders per near target

@@ -78,8 +78,8 @@ if os.environ.get("SN_EMD_DIAG"):
             w = w[:, w.sum((0, 2)) > 0, :]      # waves that exist (8-wave workgroups leave the upper rows empty)
             names2 = ["setup", "boxes", "visits (filter)", "drain batches", "final+merge", "operand wait", "#visits", "#drains",
                       "#g-blocks", "#g-blocks hit", "#enqueue rounds", "#hits", "#exact evals", "#election rounds", "enqueue", "-"]
-            per_it = 40.0
-            print("bid_group, tail iterations (it >= 10), per wave and iteration; us or counts (mean over the waves of 3 workgroups / max wave):")
+            per_it = float(os.environ.get("BID_STAMPS_ITS", "40"))   # stamped iterations (SN_STAMP_FROM .. SN_STAMP_TO of the build)
+            print(f"bid_group, {per_it:.0f} stamped iterations, per wave and iteration; us or counts (mean over the waves of 3 workgroups / max wave):")
             for i, n_ in enumerate(names2):
                 sc = 100.0 if (i < 6 or i == 14) else 1.0
                 print(f"  {n_:16s} {w[:, :, i].mean() / sc / per_it:7.2f} / {w[:, :, i].max() / sc / per_it:7.2f}")
