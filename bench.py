@@ -36,7 +36,7 @@ Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line
                     stream, against the fp32 peak; `algorithmic_*` = SURVEY 8d's 14 flop x effective pairs over
                     the same time (the pruned search skips most algorithmic pairs, so that rate can exceed the
                     peak); `wait_frac`, `valu_busy`, `mfma_busy`, `traffic`; the same block for nn_search_kernel,
-                    p2i_gather_max_kernel and (other_ops) mds_clustered_kernel
+                    p2i_gather_max_kernel and (other_ops) mds_dense_team_kernel
   cpu_baseline      the CPU oracle (port of the reference algorithm; the Chamfer single-thread leg is the
                     reference's own CPU build when oracle/_ref is present) on a bounded sample, two legs
 """
@@ -166,7 +166,7 @@ class HotPath:
         self.side = None
         self.side2 = None
         self.hi = None
-        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first[_cd_exp|_main_after]" / "chain" / "one_stream" force an order (A/B); auto: MEASURED
+        self.order = os.environ.get("BENCH_ORDER", "auto")   # "auction_first" / "chain" / "one_stream" force an order (A/B); auto: MEASURED
         self.three_streams_env = os.environ.get("BENCH_THREE_STREAMS")   # "0" / "1" force it (A/B); default: measured with the order
         # batch size -> (schedule name, {schedule: ms}) chosen by choose_schedule() during the untimed warm-up
         self.schedule = {}
@@ -259,9 +259,9 @@ class HotPath:
         against 3.16-3.45 / 2.01 / 1.78: the auction's teams leave XCDs idle there, and the chain's head overlaps the
         renderer)."""
         if self.order != "auto":
-            return self.order.startswith("auction_first")
+            return self.order == "auction_first"
         if clouds in self.schedule:
-            return self.schedule[clouds][0].startswith("auction_first")
+            return self.schedule[clouds][0] == "auction_first"
         return clouds >= 24   # before / without choose_schedule(): round 4's table
 
     def one_stream(self, clouds):
@@ -269,7 +269,7 @@ class HotPath:
             return self.order == "one_stream"
         return clouds in self.schedule and self.schedule[clouds][0] == "one_stream"
 
-    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first", "auction_first_cd_exp", "auction_first_main_after")
+    SCHEDULES = ("one_stream", "chain_2", "chain_3", "auction_first")
 
     def choose_schedule(self, pred, gt, reps=6, reduce_max=None):
         """Time every schedule on THIS batch during the untimed warm-up and keep the fastest (round 5 shipped a constant
@@ -319,18 +319,14 @@ class HotPath:
         # the auction's preparation kernels and make the persistent grid wait for them: 4.59 ms against 4.32 at 32
         # clouds, slower at every share (profiles/r06_g_strong_share.txt); what overlaps the auction's preparation and
         # tail is worth more than the clean start.  Not kept.)
-        variant = self.schedule.get(pred.size(0), ("auction_first", None))[0] if self.order == "auto" else self.order
-        if variant == "auction_first_main_after":   # Chamfer + expansion penalty only once the auction is done
-            main.wait_stream(self.hi)
+        # (Round 6 also timed two variants of this order as candidates -- Chamfer before the expansion penalty, and
+        # Chamfer + expansion only after the auction: within 1 % of this one or slower at every share
+        # (profiles/r06_m_strong_share.txt), and one more candidate each for the warm-up to choose between: removed.)
         with torch.cuda.stream(self.side):
             acc = self._render_all(pred)
         acc.record_stream(main)
-        if variant == "auction_first_cd_exp":       # the expansion penalty's 0.5 ms of lone waves last instead of first
-            loss_cd = self._loss_cd(pred, gt)
-            loss_exp = self._loss_expansion(pred)
-        else:
-            loss_exp = self._loss_expansion(pred)
-            loss_cd = self._loss_cd(pred, gt)
+        loss_exp = self._loss_expansion(pred)
+        loss_cd = self._loss_cd(pred, gt)
         main.wait_stream(self.hi)
         main.wait_stream(self.side)
         losses = torch.stack([loss_cd.detach(), loss_emd.detach(), loss_exp.detach(), acc.detach()])
@@ -1157,20 +1153,23 @@ def main():
             out["other_ops_ms_rank0"] = oo
             if roofline is not None:
                 # the sampler (outside the headline step; 2 calls per generator forward): SURVEY 8(d)'s 12 flop per
-                # point and round, 16383 dependent rounds on ONE CU per cloud (B of 256 CUs busy) -- latency bound
+                # point and round, 16383 dependent picks per cloud.  Since round 6 every cloud of this size is sampled by
+                # a TEAM of workgroups (mds_dense_team_kernel: 8 per cloud at 32 clouds) taking several exact picks per
+                # exchange; counters per workload: tools/pmc_all.sh splits the probe's three team dispatches
                 fl = 12.0 * B * (N - 1) * 19384
-                blk = {"kernel": "mds_clustered_kernel", "bound": "valu_f32", "peak": PEAK_F32_TFLOPS,
+                blk = {"kernel": "mds_dense_team_kernel", "bound": "latency", "peak": PEAK_F32_TFLOPS,
                        "unit": "TFLOP/s", "algorithmic_flops_per_launch": fl,
-                       "surface": {"ms": oo["mds_19384_to_16384_surface"],
-                                   "algorithmic_frac": fl / (oo["mds_19384_to_16384_surface"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
-                       "dense": {"ms": oo["mds_19384_to_16384"],
-                                 "algorithmic_frac": fl / (oo["mds_19384_to_16384"] * 1e-3) / 1e12 / PEAK_F32_TFLOPS},
-                       "note": "one workgroup per cloud and one pick per round: per-round latency x 16383; the culled "
-                               "update skips most of the algorithmic point-rounds (surface regime)"}
-                cbm = counters_block("mds_clustered_kernel", 1, oo["mds_19384_to_16384_surface"] * 1e-3)
-                blk.update(cbm)
-                blk["frac"] = cbm.get("executed_frac")      # counters are taken on the surface-like cloud
-                roofline["mds_clustered"] = blk
+                       "note": "a team of workgroups per cloud, several exact picks per exchange: a chain of dependent "
+                               "exchanges (update -> arg-min -> poll -> replay); the updates sit at the VALU floor, the "
+                               "culled update skips most of the algorithmic point-rounds in the surface regime"}
+                for tag, key in (("surface", "mds_19384_to_16384_surface"), ("dense", "mds_19384_to_16384")):
+                    sub = {"ms": oo[key], "algorithmic_frac": fl / (oo[key] * 1e-3) / 1e12 / PEAK_F32_TFLOPS}
+                    sub.update(counters_block(f"mds_dense_team_kernel#{tag}_b32", 1, oo[key] * 1e-3))
+                    sub["frac"] = sub.get("executed_frac")
+                    blk[tag] = sub
+                blk["frac"] = blk["dense"].get("frac")
+                blk["counters_from"] = blk["dense"].get("counters_from")
+                roofline["mds_team"] = blk
         if world == 1 and not args.no_emd_regimes:
             out["emd_regimes_rank0"] = emd_regimes(dev)
         if world == 1 and not args.no_network_steps:
