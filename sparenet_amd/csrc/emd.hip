@@ -1161,10 +1161,24 @@ __device__ __forceinline__ bool box_within(const f4 A, const f4 B, float x, floa
   const float gz = __builtin_fmaxf(__builtin_fmaxf(A.z - z, z - B.y), 0.f);
   return ((gx * gx + gy * gy) + gz * gz) * 0.9999f <= r2;
 }
+// The same with the box's OWN price bound (round 6).  B.z = A'max of the box: an upper bound of filter_target(price) over
+// its targets -- from the price floor (the same for every box) or, on contested / off-surface clouds, from the smallest
+// price the box held when the iteration began (auction_body refreshes the LDS copy; prices do not move during a bid
+// phase).  The reach is bid_group's coarse_threshold with that bound: cthr = filter_thr(bound of the bidder's final
+// `better`), base = the slack term.  A bidder far from every cheap target no longer lists the expensive near-side
+// blocks it cannot want: 20-35 % fewer blocks late in a contested call (tools/sim/auction_regime_stats.c).
+__device__ __forceinline__ bool box_within_priced(const f4 A, const f4 B, float x, float y, float z, float cthr, float base) {
+  const float r = B.z - cthr;
+  const float v = __builtin_fmaf(r * __builtin_fabsf(r), 1.00000095367431640625f, base);
+  return box_within(A, B, x, y, z, v > 0.f ? v * 1.0001f : v);
+}
 
 #define SN_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), ctrl, 0xf, 0xf, true))
 #define SN_DPP_I(v, ctrl) __builtin_amdgcn_mov_dpp(v, ctrl, 0xf, 0xf, true)
 
+#ifndef SN_EMD_BMIN_EVERY
+#define SN_EMD_BMIN_EVERY 4   // contested iterations between two refreshes of the boxes' price bounds
+#endif
 #ifndef SN_SCAN_RESHARE
 #define SN_SCAN_RESHARE 0  // > 0: the lanes share their bound again every that many rounds (see bid_scan)
 #endif
@@ -1204,7 +1218,8 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
     const int u = u0 + (qd >> tsh), part = qd & (T - 1);
     const bool active = u < count;  // uniform within the quarter
     int jj = 0, rank = 0, ba = -1, bb = -1;  // ba, bb: the blocks of the two previous favourites
-    float x1 = 0.f, y1 = 0.f, z1 = 0.f, cm = -1e9f, r2 = -3.0e38f;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f, cm = -1e9f;
+    float cthr = 3.0e38f, base = 0.f;  // the reach of a box = coarse_threshold(cm, base, the box's A'max): box_within_priced
     if (active) {
       // two round trips: {coordinates, previous favourites} of the bidder, then the favourites' coordinates and
       // prices BY INDEX (the caller's array and the price array of the award phase; their stream positions, needed
@@ -1232,8 +1247,8 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       {
 #pragma clang fp contract(off)
         const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
-        const float v = coarse_threshold(cm, 2.f * 3.814697265625e-06f * (c.tmax + xx), c.a_max);
-        r2 = v > 0.f ? v * 1.0001f : v;
+        base = 2.f * 3.814697265625e-06f * (c.tmax + xx);
+        cthr = filter_thr(cm);
       }
     }
     Top2 top = {-1e9f, -1e9f, -1, -1};
@@ -1245,7 +1260,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
 #pragma unroll
     for (int h0 = 0; h0 < kScanBlk / 16; h0 += 16) {  // nh <= 64: the four turns' box reads go out together
       const int h = h0 + col < nh ? h0 + col : 0;
-      const bool w = h0 + col < nh && box_within(SL.hb[h][0], SL.hb[h][1], x1, y1, z1, r2);
+      const bool w = h0 + col < nh && box_within_priced(SL.hb[h][0], SL.hb[h][1], x1, y1, z1, cthr, base);
       hm |= ((__ballot(w) >> (16 * row)) & 0xffffull) << h0;
     }
     auto fetch = [&](ScanCand &B, int i, int cnt) {
@@ -1335,8 +1350,8 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
           hm = two ? hm & (hm - 1ull) : hm;
           const int s0 = 16 * h0 + col, s1 = 16 * h1 + col;
           const f4 a0 = SL.blk[s0][0], c0 = SL.blk[s0][1], a1 = SL.blk[s1][0], c1 = SL.blk[s1][1];
-          const bool w0 = s0 != ba && s0 != bb && box_within(a0, c0, x1, y1, z1, r2);
-          const bool w1 = two && s1 != ba && s1 != bb && box_within(a1, c1, x1, y1, z1, r2);
+          const bool w0 = s0 != ba && s0 != bb && box_within_priced(a0, c0, x1, y1, z1, cthr, base);
+          const bool w1 = two && s1 != ba && s1 != bb && box_within_priced(a1, c1, x1, y1, z1, cthr, base);
           const unsigned b0 = (unsigned)((__ballot(w0) >> (16 * row)) & 0xffffull);
           const unsigned b1 = (unsigned)((__ballot(w1) >> (16 * row)) & 0xffffull);
           const unsigned below = (1u << col) - 1u;
@@ -1398,9 +1413,7 @@ __device__ __forceinline__ void bid_scan(const BidCtx &c, ScanLds &SL, const int
       if (c.offsurf && __any(hm != 0ull)) {
 #pragma clang fp contract(off)
         share();
-        const float xx = (x1 * x1 + y1 * y1) + z1 * z1;
-        const float v = coarse_threshold(__builtin_fmaxf(cm, qlb), 2.f * 3.814697265625e-06f * (c.tmax + xx), c.a_max);
-        r2 = active ? (v > 0.f ? v * 1.0001f : v) : r2;
+        cthr = active ? filter_thr(__builtin_fmaxf(cm, qlb)) : cthr;
       }
 #endif
       STAMP(2)
@@ -1652,8 +1665,17 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         L.scan.hb[h][1] = hi;
       }
       __syncthreads();
+      // the boxes' price bounds (the free third word of a row's second half; see box_within_priced): the price floor's
+      // for a start -- prices only rise for eps >= 0, so it stays valid until an iteration refreshes it
+      {
+        const float amax0 = filter_target(0.f) + 9.5367431640625e-07f;
+        for (int i = tid; i < 4 * nsb; i += kBidThreads) L.scan.blk[i][1].z = amax0;
+        for (int h = tid; h < (nsb >> 2); h += kBidThreads) L.scan.hb[h][1].z = amax0;
+      }
+      __syncthreads();
     }
 
+    int bmin_it = -1000;  // the iteration of the last refresh of the boxes' price bounds (see the bid phase)
     for (int it = 0; it < a.iters; ++it) {
       const int cur = it & 1;
       // (Round 4 measured a deterministic COST-weighted split here -- every bin weighted with the work bid_scan's
@@ -1855,6 +1877,37 @@ __device__ __forceinline__ void auction_body(const AuctionArgs &a) {
         c.offsurf = contested || far;
         const int scan_max = ((contested || far) && a.scan_max > 0 && a.scan_max < kScanContested) ? kScanContested : a.scan_max;
         if (scan_ok && Um <= scan_max) {  // uniform in the workgroup: a quarter wave per bidder
+#ifndef SN_EMD_NO_BMIN
+          if (contested && a.eps >= 0.f && it - bmin_it >= SN_EMD_BMIN_EVERY) {
+            // CONTESTED clouds: every box's bound from the SMALLEST PRICE it holds now (prices do not move during a bid
+            // phase).  A bidder there sits far from the surface, the near-side targets' prices have climbed, and with the
+            // price floor's bound their blocks -- which it can no longer want -- stay within its reach.  The refresh
+            // costs 11-15 us per workgroup (16 coherent loads per thread + two barriers): in every iteration of every
+            // off-surface cloud it made the SCATTERED regime slower (3.9 -> 4.45 ms per call at 32 clouds, its prices stay
+            // low) while the untrained regime gained (31.2 -> 26.7): hence contested iterations only, and every fourth
+            // one -- a bound from earlier, lower prices stays valid (eps >= 0: prices only rise).
+            bmin_it = it;
+            for (int bq = tid; bq < 4 * nsb; bq += kBidThreads) {
+              const float2 *pp = c.pkc + 16 * bq;
+              float pm = 3.0e38f;
+#pragma unroll 8
+              for (int i = 0; i < 16; ++i) pm = __builtin_fminf(pm, ldc_pk(pp + i).x);
+              L.scan.blk[bq][1].z = filter_target(pm) + 9.5367431640625e-07f;
+            }
+            __syncthreads();
+            for (int h = tid; h < (nsb >> 2); h += kBidThreads) {
+              float mx = L.scan.blk[16 * h][1].z;
+              for (int q = 1; q < 16; ++q) mx = __builtin_fmaxf(mx, L.scan.blk[16 * h + q][1].z);
+              L.scan.hb[h][1].z = mx;
+            }
+            __syncthreads();
+          } else
+#endif
+          if (a.eps < 0.f) {  // prices may fall: this iteration's price floor for every box
+            for (int i = tid; i < 4 * nsb; i += kBidThreads) L.scan.blk[i][1].z = c.a_max;
+            for (int h = tid; h < (nsb >> 2); h += kBidThreads) L.scan.hb[h][1].z = c.a_max;
+            __syncthreads();
+          }
           bid_scan(c, L.scan, llist, Um, wave, lane);
         } else {
           const int ngroups = (Um + 63) >> 6;
