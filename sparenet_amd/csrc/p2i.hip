@@ -1154,6 +1154,9 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
     for (int tx = wave; tx < kAccRegion; tx += 4) {
       const int cx = rx * kAccRegion + tx, cy = ry * kAccRegion + ty;
       if (cx >= cells_x || cy >= cells_y) continue;  // wave-uniform
+      // (Measured and not kept, round 6: a wave's 64 pixels as an 8 x 8 lattice of spacing 4 over the region, so that
+      // same-winner neighbours land in different LDS instructions: render 2.03 -> 2.15 ms, the strided reads cost more
+      // than the conflicts: profiles/r06_p_accum_lattice_not_kept.txt.)
       const int x = cx * kCell + (lane & 7), y = cy * kCell + (lane >> 3);
       const bool valid = x < w && y < h;
       const size_t e = plane + (size_t)(valid ? y : 0) * w + (valid ? x : 0);
