@@ -19,8 +19,9 @@ print({k: d[k] for k in ("value", "ms_per_step", "depthmaps_per_sec", "depthmaps
 print("config", d["config"].get("order"), d["config"].get("streams"), d["config"].get("schedule_table_ms"))
 print("segments", d["segments_ms_rank0"])
 print("roofline", {k: r.get(k) for k in ("kernel", "bound", "achieved", "frac", "frac_basis", "algorithmic_frac", "wait_frac", "valu_busy", "mfma_busy", "traffic", "avg_launch_us", "counters_from")}, "live", r.get("live"))
-for k in ("chamfer_fwd", "p2i_gather_max", "mds_clustered"):
+for k in ("chamfer_fwd", "p2i_gather_max"):
     print(k, {a: r[k].get(a) for a in ("frac", "algorithmic_frac", "valu_busy", "wait_frac", "avg_launch_us", "search_kernel_avg_us", "traffic") if a in r[k]})
+print("mds_team", {t: {a: d["roofline"]["mds_team"][t].get(a) for a in ("ms", "frac", "algorithmic_frac", "valu_busy", "wait_frac", "counters_from")} for t in ("surface", "dense")} if "mds_team" in d["roofline"] else None)
 print("literal", d.get("literal_radii"))
 print("emd regimes", {k: round(v, 3) for k, v in d.get("emd_regimes_rank0", {}).items() if k != "note"})
 ns = d.get("network_steps_rank0", {})
