@@ -182,7 +182,12 @@ int sn_expansion_backward(const float *xyz, const float *graddist,
  *          kernel MDS_cuda.cu:91-268).  idx[b,m] int32, m <= n.
  * The `temp` tensor MDS.cpp:119-121 allocates lives in registers; only clouds
  * with more than 24576 points need `workspace` (sn_mds_workspace_bytes() > 0).
- * The density kernel is sn_expf (include/sn_expf.h), not libm/OCML expf. */
+ * The density kernel is sn_expf (include/sn_expf.h), not libm/OCML expf.
+ * Clouds of 2048 .. 20352 points are cluster-sorted and sampled either by one workgroup each or by a TEAM of up to
+ * 32 workgroups per cloud that takes several exact picks per exchange (every cloud of >= 8192 points when teams of
+ * >= 8 fit the device; index sequences are the reference's either way).  A team's bounded waits can give up when the
+ * device is shared with something that keeps compute units from the launch: the row is then -1 and the next sn_mds /
+ * sn_emd_* call -- or sn_device_status() -- reports SN_ETIMEDOUT. */
 size_t sn_mds_workspace_bytes(int b, int n);
 int sn_mds(const float *xyz, int b, int n, int m, const float *mean_mst_length,
            int *idx, void *workspace, size_t workspace_bytes, void *stream);

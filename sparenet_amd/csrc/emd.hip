@@ -43,6 +43,9 @@
 //     serves a bidder, in which order, and whether a certain loser is linked never enter a result.
 //   * A raised flag IS the bidder's index (+ 1) and the index travels in the bid record: neither the compaction nor
 //     the award phase looks anything up in the permutation.
+//   * Round 6: in the per-bidder scan a box of 16 (or 256) targets is tested against a reach computed from the box's OWN
+//     price bound (box_within_priced); on contested clouds that bound is the smallest price the box holds, refreshed
+//     in LDS every fourth contested iteration -- a far bidder no longer lists the expensive near-side blocks.
 #include <atomic>
 #include <chrono>
 #include <cstdlib>

@@ -7,8 +7,11 @@
 // reference's reduction tree induces.  The exponential is sn_expf (shared with the
 // oracle, include/sn_expf.h).
 //
-// MI355X design: the op is 16383 DEPENDENT rounds per cloud, so the lever is the
-// latency of one round.  One workgroup (bs <= 1024 lanes = 16 waves = one CU) owns a
+// MI355X design: the op is 16383 DEPENDENT picks per cloud, so the levers are the latency of one
+// round and -- since round 6, on the team kernel that serves SpareNet-sized clouds -- several exact
+// picks per exchange between the workgroups of a cloud (mds_dense_team_kernel below).  The
+// one-workgroup kernels (small clouds, teams that cannot be formed, graph capture):
+// One workgroup (bs <= 1024 lanes = 16 waves = one CU) owns a
 // cloud and keeps the WHOLE state in registers: lane tid owns points tid, tid+bs, ...
 // (coordinates + density, 4 VGPRs per point, 19 points per lane at n = 19384) -- the
 // reference re-reads xyz and read-modify-writes `temp` in global memory every round.
@@ -507,26 +510,28 @@ __global__ __launch_bounds__(1024) void mds_clustered_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
-// Dense regime on a TEAM of workgroups (mds_dense_team_kernel).
-// When the cut ball covers most of the cloud every slot is updated in every round and a round is bound by the
-// vector ALUs of the ONE compute unit that owns the cloud (4.3 us x 16383 rounds = 68 ms at n = 19384, whatever
-// the batch: 32 of 256 CUs busy at B = 32, 4 at the 8-GPU share).  Here G workgroups share a cloud: workgroup g
-// keeps the slots [g PG, (g + 1) PG) of the cluster-sorted cloud, updates them, finds its own arg-min exactly as
-// the single-workgroup kernel does, and the G candidates meet in global memory:
-//   * one 64-bit word per workgroup and round, {density bits : 32 | low key : 26 | round stamp : 6}, in a ring of
-//     two rounds, written with ONE agent-scope store and polled with agent-scope loads by lanes 0 .. G-1 of every
-//     wave (a word is either entirely of this round or not: no fence, no flag + data pair);
-//   * the minimum over the G words (density, then the reference's tie key) is the pick; its coordinates are read
-//     from xyz (constant data, one uniform load).
-//   A workgroup can only run two rounds ahead of the slowest member (round j + 1 needs everybody's round-j word),
-//   so the two-deep ring never overwrites a word somebody still needs.
+// A cloud on a TEAM of workgroups (mds_dense_team_kernel; the name is round 3's, when only the dense regime took it).
+// With one workgroup per cloud a round is bound by the vector ALUs of the ONE compute unit that owns the cloud (4.3 us
+// x 16383 rounds = 68 ms at n = 19384 when the cut ball covers the cloud, whatever the batch: 32 of 256 CUs busy at
+// B = 32, 4 at the 8-GPU share).  Here G <= 32 workgroups share a cloud: member g keeps PG x nw consecutive groups of
+// 64 points of the cluster-sorted cloud (dealt out evenly), updates them, finds its own arg-min exactly as the
+// single-workgroup kernel does, and the G candidates meet in global memory:
+//   * four 64-bit words per member and EXCHANGE in the member's own cache line, each with the exchange's 6-bit stamp
+//     (a word is either entirely of this exchange or not: no fence, no flag + data pair), in a ring of two exchanges:
+//     the member's lowest key (density bits : 32 | tie key : 26), its SECOND lowest density, the candidate's
+//     coordinates; written by lanes 0-3 of wave 0, polled with agent-scope loads by lanes 0 .. G-1 of wave 0;
+//   * every member then replays the same picks among the G candidates (round 6: several exact picks per exchange,
+//     see the loop) and applies them in pick order.
+//   A member can only run two exchanges ahead of the slowest one (exchange e + 1 needs everybody's words of e), so
+//   the two-deep ring never overwrites a word somebody still needs.
 // Teams are formed from XCD-local tickets like the auction's (emd.hip): the G workgroups of a cloud sit on one
 // XCD whenever the dispatcher allows it, so the words travel through that XCD's L2; any placement is correct.
 // Every poll is bounded: on a time-out the launch raises its abort word and the device's sticky word (the next
 // sn_mds / sn_emd_* call fails with SN_ETIMEDOUT), and the cloud's whole index row is written as -1 (which
 // sn_gather_forward turns into NaN features: never a plausible-looking sample).
-// Only clouds in the dense regime take this path (the predicate is the single-workgroup kernel's, which skips
-// exactly those clouds); index sequences are identical by construction -- the arg-min is order independent.
+// Which clouds take this path: cut^2 > team_ratio x (bounding box diagonal)^2, the predicate by which the
+// single-workgroup kernel skips exactly those clouds; since round 6 team_ratio is ~0 for clouds of >= 8192 points on
+// teams of >= 8 (every regime; see sn_mds).  Index sequences are identical by construction.
 // ---------------------------------------------------------------------------------------
 struct MdsTeamCtl {          // zeroed before the launch
   unsigned xticket[8];

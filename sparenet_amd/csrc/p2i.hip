@@ -1169,44 +1169,66 @@ __global__ __launch_bounds__(256) void p2i_max_bwd_accum_kernel(
         gk[k] = (k < nradii && valid) ? out_grad[(size_t)k * orstride + oe] : 0.f;
         pidk[k] = (k < nradii && valid) ? out_ids[(size_t)k * orstride + oe] : -1;
       }
+      // The radii of a pixel often share their winner (the same point wins at 5, 7 and 10 pixels): consecutive equal
+      // winners are summed in registers and meet the table once (round 6; integer sums are exact in any order).
+      int ppid = -1;
+      unsigned long long p0 = 0ull, p1 = 0ull, p2 = 0ull;
 #pragma unroll
-      for (int k = 0; k < kMaxRadii; ++k) {
-        if (k >= nradii) break;
-        const int pid = pidk[k];
-        if (pid < 0) {
-          bg += gk[k];
+      for (int k = 0; k <= kMaxRadii; ++k) {
+        if (k > nradii) break;
+        int pid = -1;
+        unsigned long long t0 = 0ull, t1 = 0ull, t2 = 0ull;
+        if (k < kMaxRadii && k < nradii) {
+          pid = pidk[k];
+          if (pid < 0) {
+            bg += gk[k];
+          } else {
+            // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of
+            // the reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
+            const float2 pp = reinterpret_cast<const float2 *>(points)[pid];  // {row, column}
+            const float fv = feat[(size_t)pid * channels + c];
+            const float dx = x - pp.y, dy = y - pp.x;
+            const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
+            const float cf = gk[k] * weight32(u);
+            const float kk = gk[k] * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
+            t0 = fixed(cf);
+            t1 = fixed(kk * dy);
+            t2 = fixed(kk * dx);
+          }
+        }
+        if (pid >= 0 && pid == ppid) {  // the same winner as the previous radius: one table entry for both
+          p0 += t0;
+          p1 += t1;
+          p2 += t2;
           continue;
         }
-        // weight and slope as fp32 series in u = r^2 / R^2 (no square root, no division, no fp64): within 5e-7 of the
-        // reference's fp32 cos / sin; the kernel was bound by the fp64 sincos of every term
-        const float py = points[pid * 2 + 0], px = points[pid * 2 + 1];
-        const float fv = feat[(size_t)pid * channels + c];
-        const float dx = x - px, dy = y - py;
-        const float u = __builtin_fminf((dx * dx + dy * dy) * ra.inv_r2[k], 1.0f);
-        const float cf = gk[k] * weight32(u);
-        const float kk = gk[k] * fv * (4.93480220f * ra.inv_r2[k]) * slope32(u);  // pi^2 / 2
-        const unsigned long long t0 = fixed(cf), t1 = fixed(kk * dy), t2 = fixed(kk * dx);
-        // (Round 5 merged the terms of neighbouring pixels with the same winner -- lane ^ 1, then lane ^ 8 -- before
-        // the table's atomics: exact, and no faster; removed.)
-        unsigned slot = (((unsigned)pid * 2654435761u) >> 16) & (kAccSlots - 1);
-        bool found = false;
-        for (int probe = 0; probe < kAccProbes; ++probe) {
-          const int prev = atomicCAS(&keys[slot], -1, pid);
-          if (prev == -1 || prev == pid) {
-            found = true;
-            break;
+        if (ppid >= 0) {
+          // (Round 5 merged the terms of neighbouring pixels with the same winner -- lane ^ 1, then lane ^ 8 -- before
+          // the table's atomics: exact, and no faster; removed.)
+          unsigned slot = (((unsigned)ppid * 2654435761u) >> 16) & (kAccSlots - 1);
+          bool found = false;
+          for (int probe = 0; probe < kAccProbes; ++probe) {
+            const int prev = atomicCAS(&keys[slot], -1, ppid);
+            if (prev == -1 || prev == ppid) {
+              found = true;
+              break;
+            }
+            slot = (slot + 1) & (kAccSlots - 1);
           }
-          slot = (slot + 1) & (kAccSlots - 1);
+          if (found) {
+            atomicAdd(&vals[slot][0], p0);
+            atomicAdd(&vals[slot][1], p1);
+            atomicAdd(&vals[slot][2], p2);
+          } else {  // a crowded table: integer sums are exact in any order
+            atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)ppid * channels + c), p0);
+            atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)ppid * 2 + 0), p1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)ppid * 2 + 1), p2);
+          }
         }
-        if (found) {
-          atomicAdd(&vals[slot][0], t0);
-          atomicAdd(&vals[slot][1], t1);
-          atomicAdd(&vals[slot][2], t2);
-        } else {  // a crowded table: integer sums are exact in any order
-          atomicAdd(reinterpret_cast<unsigned long long *>(acc_feat + (size_t)pid * channels + c), t0);
-          atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 0), t1);
-          atomicAdd(reinterpret_cast<unsigned long long *>(acc_pts + (size_t)pid * 2 + 1), t2);
-        }
+        ppid = pid;
+        p0 = t0;
+        p1 = t1;
+        p2 = t2;
       }
       if (valid && background_grad) background_grad[e] = bg;
     }
