@@ -212,3 +212,33 @@ def test_hip_dense_regime_teams_and_mixed_batches(b, n, m, dev):
     assert np.array_equal(got, want)
     got2 = _hip_mds(x, m, mm, dev)          # run to run: the exchange is deterministic
     assert np.array_equal(got, got2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,n,m,mml,kind", [
+    (4, 2048, 2048, 0.2, "uniform"),        # m == n on a team: the last exchanges find nothing below 1e9 but one point
+    (2, 8192, 8192, 0.004, "uniform"),      # m == n, surface regime, teams of 32: the pick cap (16 per exchange) saturates
+    (3, 19384, 6000, 0.05, "duplicates"),   # exact duplicates: equal densities, the tie key decides inside the replay
+    (8, 19384, 3000, 0.0085, "sphere"),     # teams of 32 in the surface regime (every cloud on a team since round 6)
+    (9, 19384, 2000, 0.03, "uniform"),      # 9 clouds: two teams per XCD, teams of 16
+    (1, 8192, 4000, 1e-4, "uniform"),       # all-zero densities: the picks are the tie rule's order, candidate by candidate
+])
+def test_hip_team_multi_pick_corner_cases(b, n, m, mml, kind, dev):
+    """Round 6's team kernel: several exact picks per exchange (each member's lowest candidate with its coordinates +
+    its second-lowest density; the replay accepts a pick only strictly below every member's second-lowest), members
+    owning evenly dealt groups of 64 points, teams of up to 32.  Index-exact against the oracle where a replay error
+    would show: everything selected, duplicated points, ties, both regimes, several team geometries."""
+    rng = np.random.default_rng(n * 7 + m + b)
+    if kind == "sphere":
+        v = rng.standard_normal((b, n, 3)).astype(np.float32)
+        x = (0.5 * v / np.linalg.norm(v, axis=2, keepdims=True)).astype(np.float32)
+    else:
+        x = rng.random((b, n, 3), dtype=np.float32)
+    if kind == "duplicates":
+        x[:, n // 2:] = x[:, :n - n // 2]     # every point twice
+    mm = (mml * (1 + 0.1 * rng.random(b))).astype(np.float32)
+    want = oracle.mds(x, m, mm, exp_mode=1)
+    got = _hip_mds(x, m, mm, dev)
+    assert np.array_equal(got, want)
+    if m == n:
+        assert all(len(set(r.tolist())) == n for r in got)
